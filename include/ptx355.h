@@ -1,0 +1,176 @@
+/* ptx355 — C ABI of the MI355X path-tracing compute pass.
+ *
+ * This is the drop-in boundary for the reference's frame-dispatch / accumulator seam.  The reference
+ * (a Rust/wgpu application) has no FFI of its own; the seam these entry points replace is the set of
+ * wgpu calls its frame loop makes around the `path_trace` compute pipeline.  Each declaration cites
+ * the reference code it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions: plain pointers and sizes, no exceptions; every call returns 0 on success or a negative
+ * ptx_status; ptx_last_error() gives the message.  One context = one HIP device + one stream, driven
+ * by one thread at a time (as the reference drives everything from its event-loop thread).  Caller
+ * owns every array it passes; the library copies during the call.  ptx_trace* enqueue asynchronously;
+ * ptx_read_* and ptx_sync synchronise.
+ */
+#ifndef PTX355_H
+#define PTX355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- records, byte-identical to the reference's #[repr(C)] Pod structs ------------------------ */
+
+/* src/camera/camera.rs:150-171 (WGSL Camera, src/shaders/wgsl/types.wgsl:3-22).  112 bytes. */
+typedef struct ptx_camera {
+    float position[3]; float focal_length;
+    float right[3];    float aspect;
+    float up[3];       float exposure;
+    float forward[3];  uint32_t frame_index;
+    uint32_t width, height, sample_count, max_bounces;
+    uint32_t tone_mapper, fractal_march_steps; float firefly_clamp, skybox_brightness;
+    float skybox_color[3]; float _pad2;
+} ptx_camera;
+
+/* src/scene/shape.rs:223-248 (WGSL Figure, types.wgsl:24-41).  112 bytes.  _pad2.._pad4 carry the
+ * per-vertex UVs of triangles as two binary16 values each (shape.rs:272-276). */
+typedef struct ptx_shape {
+    uint32_t shape_type, material_idx; float radius, radius2;
+    float position[3]; float height;
+    float normal[3];   uint32_t csg_op;
+    float rotation[3]; float texture_scale;
+    float v0[3]; uint32_t _pad2;
+    float v1[3]; uint32_t _pad3;
+    float v2[3]; uint32_t _pad4;
+} ptx_shape;
+
+/* src/scene/material.rs:108-119 (WGSL Material, types.wgsl:43-52).  48 bytes. */
+typedef struct ptx_material {
+    float base_color[3]; float metallic;
+    float emission[3];   float roughness;
+    float emission_strength, ior, transmission; int32_t texture_id;
+} ptx_material;
+
+/* src/accel/bvh.rs:12-19 (WGSL BvhNode, types.wgsl:54-59).  32 bytes.  Left child = index + 1. */
+typedef struct ptx_bvh_node {
+    float aabb_min[3]; uint32_t left_or_prim;
+    float aabb_max[3]; uint32_t prim_count;
+} ptx_bvh_node;
+
+/* src/io/texture_atlas.rs:10-18.  16 bytes; `offset` counts pixels. */
+typedef struct ptx_texture_info { uint32_t width, height, offset, _pad; } ptx_texture_info;
+
+typedef enum ptx_status {
+    PTX_OK = 0,
+    PTX_ERR_BAD_ARG = -1,
+    PTX_ERR_HIP = -2,
+    PTX_ERR_OOM = -3,
+    PTX_ERR_STATE = -4,       /* call order: e.g. trace before upload/resize */
+    PTX_ERR_UNSUPPORTED = -5  /* scene outside what the kernels accept (see ptx_upload_scene) */
+} ptx_status;
+
+typedef struct ptx_ctx ptx_ctx;
+
+/* Work tallies since the last ptx_clear: paths = pixel-samples finished, bounces = closest-hit traces
+ * issued by the bounce loop (one per path·bounce), shadow_rays = NEE occlusion queries. */
+typedef struct ptx_stats { uint64_t paths, bounces, shadow_rays; } ptx_stats;
+
+/* Device and stream set-up: replaces GpuContext::new (src/gpu/context.rs:17-82) minus window/surface. */
+int ptx_create(int device, ptx_ctx** out);
+void ptx_destroy(ptx_ctx* ctx);
+const char* ptx_last_error(const ptx_ctx* ctx);
+
+/* Scene upload: replaces AppState::create_geometry_buffers and the two texture buffers
+ * (src/app/state.rs:389-446, 179-182) and bind group 1 (state.rs:717-741, 833-883).  Counts are
+ * explicit: pass the real lists, NOT the reference's one-element placeholder buffers
+ * (state.rs:381-387, 404-422); an empty light list still makes the NEE branch consume its three random
+ * numbers, as the reference's placeholder does.  Figures are re-laid-out on the device.
+ * PTX_ERR_UNSUPPORTED: a leaf with more than 7 primitives, more than 2^29 nodes or primitives, or an
+ * index out of range. */
+int ptx_upload_scene(ptx_ctx* ctx,
+                     const ptx_shape* figures, uint32_t n_figures,
+                     const ptx_material* materials, uint32_t n_materials,
+                     const ptx_bvh_node* bvh_nodes, uint32_t n_nodes,
+                     const uint32_t* bvh_prims, uint32_t n_prims,
+                     const uint32_t* light_indices, uint32_t n_lights,
+                     const uint32_t* infinite_indices, uint32_t n_infinite,
+                     const uint32_t* tex_pixels, uint32_t n_pixels,
+                     const ptx_texture_info* tex_infos, uint32_t n_textures);
+
+/* Frame size: replaces recreate_size_dependent_resources (src/app/state.rs:492-535).  Allocates the
+ * accumulation (w*h*16 B), output (w*h*4 B), primary-id and moment buffers, zeroed; resets the tile to
+ * the full frame. */
+int ptx_resize(ptx_ctx* ctx, uint32_t width, uint32_t height);
+
+/* Restricts ptx_trace* to the pixel rectangle [x0, x0+w) x [y0, y0+h).  No reference counterpart (the
+ * reference always dispatches the full frame, src/render/frame.rs:57-61); used to partition a frame
+ * across GPUs.  Pixel values do not depend on the tiling. */
+int ptx_set_tile(ptx_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
+
+/* encoder.clear_buffer(accumulation) (src/app/rendering.rs:110-112); also zeroes moments and stats. */
+int ptx_clear(ptx_ctx* ctx);
+
+/* One sample per pixel: the camera-uniform write plus dispatch_path_trace
+ * (src/app/rendering.rs:75-81, 114-120; src/render/frame.rs:7-22).  Uses cam->frame_index and
+ * cam->sample_count exactly as path_trace.wgsl:36,47 do; cam->width/height must equal the frame size. */
+int ptx_trace(ptx_ctx* ctx, const ptx_camera* cam);
+
+/* n samples per pixel in one launch; bit-identical to n calls of ptx_trace with
+ * frame_index = first_frame + k and sample_count = first_sample + k (k = 0..n-1), which is what n
+ * iterations of the reference's frame loop do (src/app/rendering.rs:72-82, src/render/accumulator.rs:31-36).
+ * The output image is tone-mapped from the final mean, i.e. it equals the last frame's. */
+int ptx_trace_n(ptx_ctx* ctx, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n);
+
+int ptx_sync(ptx_ctx* ctx);
+
+/* Read-back: replaces copy_texture_to_buffer + map_async (src/app/rendering.rs:314-386).
+ * accum: w*h*4 floats (rgb mean, a = 1 once written); output: w*h*4 bytes rgba8unorm. */
+int ptx_read_accum(ptx_ctx* ctx, float* rgba_f32);
+int ptx_read_output(ptx_ctx* ctx, uint8_t* rgba8);
+
+/* Parity hooks (no reference counterpart): figure index hit by the camera ray of the most recent
+ * sample of each pixel (0xFFFFFFFF = miss), w*h u32; and per-sample radiance capture for the next
+ * traces: ptx_debug_capture(ctx, max_samples) allocates max_samples * tile_w * tile_h * 3 floats
+ * (0 disables), ptx_read_debug_radiance copies the first n captured samples in tile order. */
+int ptx_read_primary_ids(ptx_ctx* ctx, uint32_t* ids);
+int ptx_debug_capture(ptx_ctx* ctx, uint32_t max_samples);
+int ptx_read_debug_radiance(ptx_ctx* ctx, float* out, uint32_t n);
+
+/* Welford second moments (no reference counterpart; the reference keeps only the mean,
+ * path_trace.wgsl:44-49).  When enabled, each pixel also accumulates M2 per channel so that per-GPU
+ * partial renders can be merged with Chan's formula.  m2: w*h*3 floats. */
+int ptx_enable_moments(ptx_ctx* ctx, int enable);
+int ptx_read_moments(ptx_ctx* ctx, float* m2);
+
+/* Device-side access for collectives (RCCL via any host framework): raw device pointers to the
+ * accumulation (w*h*4 f32) and M2 (w*h*3 f32) buffers of this context. */
+void* ptx_device_accum(ptx_ctx* ctx);
+void* ptx_device_moments(ptx_ctx* ctx);
+
+/* Chan's parallel merge of another partial render into this context's (mean, M2), per pixel, over
+ * the pixel range [first_pixel, first_pixel + n_pixels): n_a samples here, n_b samples in the other.
+ * other_mean4 / other_m2 are DEVICE pointers to n_pixels*4 / n_pixels*3 floats.  Then re-tonemaps
+ * those pixels into the output image. */
+int ptx_merge_moments(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, uint32_t n_a,
+                      const void* other_mean4, const void* other_m2, uint32_t n_b, const ptx_camera* cam);
+
+int ptx_read_stats(ptx_ctx* ctx, ptx_stats* out);
+
+/* Sum of the trace kernels' durations (HIP events on the context's stream) and their count since the
+ * last call; synchronises. */
+int ptx_kernel_time(ptx_ctx* ctx, float* total_ms, uint32_t* launches);
+
+/* Unit hooks for known-answer tests, evaluated on the device.
+ * ptx_kat_math: op 0 sin, 1 cos, 2 asin, 3 acos, 4 log, 5 log2, 6 exp2, 7 atan2(a,b), 8 pow(a,b),
+ *   9 min(a,b), 10 max(a,b); host arrays of n floats.
+ * ptx_kat_trace: closest-hit figure index / t and (if max_t != NULL) shadow occlusion for n host rays
+ *   (6 floats each: origin, direction) against the uploaded scene; cam supplies fractal_march_steps. */
+int ptx_kat_math(ptx_ctx* ctx, int op, uint32_t n, const float* a, const float* b, float* out);
+int ptx_kat_trace(ptx_ctx* ctx, const ptx_camera* cam, uint32_t n, const float* rays, const float* max_t,
+                  uint32_t* hit_id, float* hit_t, uint32_t* shadow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

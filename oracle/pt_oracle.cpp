@@ -1459,7 +1459,8 @@ void pto_rand_sequence(u32 px, u32 py, u32 frame, u32 n, float* out) {
     init_rng(c, px, py, frame);
     for (u32 i = 0; i < n; i++) out[i] = rand_f32(c);
 }
-// op: 0 sin, 1 cos, 2 asin, 3 acos, 4 log, 5 log2, 6 exp2, 7 atan2(a,b), 8 pow(a,b), 9 min, 10 max
+// op: 0 sin, 1 cos, 2 asin, 3 acos, 4 log, 5 log2, 6 exp2, 7 atan2(a,b), 8 pow(a,b), 9 min, 10 max,
+// 11 sqrt, 12 a/b, 13 fma(a,b,a)
 void pto_math(int op, u32 n, const float* a, const float* b, float* out) {
     for (u32 i = 0; i < n; i++) {
         switch (op) {
@@ -1474,6 +1475,9 @@ void pto_math(int op, u32 n, const float* a, const float* b, float* out) {
             case 8: out[i] = dm::pow_(a[i], b[i]); break;
             case 9: out[i] = dm::fmin_(a[i], b[i]); break;
             case 10: out[i] = dm::fmax_(a[i], b[i]); break;
+            case 11: out[i] = sqrtf(a[i]); break;
+            case 12: out[i] = a[i] / b[i]; break;
+            case 13: out[i] = fmaf(a[i], b[i], a[i]); break;
             default: out[i] = 0.0f;
         }
     }

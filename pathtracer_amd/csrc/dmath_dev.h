@@ -1,0 +1,193 @@
+// Deterministic binary32 math for the gfx950 kernels.
+//
+// The reference shader's sin/cos/atan2/asin/acos/log/pow are WGSL builtins with ULP-bounded,
+// implementation-defined results.  The kernels use one fixed conforming implementation built only from
+// IEEE add/sub/mul/div/sqrt/fma, round-to-nearest conversions and bit operations, so that results are
+// reproducible bit for bit on any IEEE machine (Cephes single-precision polynomials: sinf.c, atanf.c,
+// asinf.c, logf.c, exp2f.c).  Compile with -ffp-contract=off: the only fused operations are the
+// explicit __builtin_fmaf calls.  hipcc's default correctly-rounded f32 divide/sqrt is required.
+//
+// Reference call sites: src/shaders/wgsl/utils.wgsl:22, materials.wgsl:46, lighting.wgsl:14-15,
+// figures/{sphere,cylinder,cone,torus,ellipsoid,paraboloid,hyperboloid,mebius,mandelbulb,julia,skybox}.wgsl,
+// tonemap.wgsl:21.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_DEV static __device__ __forceinline__
+
+namespace dm {
+
+PT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
+PT_DEV float u2f(uint32_t u) { return __uint_as_float(u); }
+PT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// v_min_f32 / v_max_f32: IEEE minNum/maxNum, -0 < +0.
+PT_DEV float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+PT_DEV float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_DEV float sqrt_(float a) { return __builtin_sqrtf(a); }
+PT_DEV float abs_(float a) { return __builtin_fabsf(a); }
+
+#define DM_PIO2 1.57079632679489661923f
+#define DM_PI 3.14159265358979323846f
+#define DM_PIO4 0.78539816339744830962f
+
+PT_DEV void sincos_(float x, float* s_out, float* c_out) {
+    float k = __builtin_rintf(x * 0.63661977236758134f);
+    float r = fma_(-k, 1.5703125f, x);
+    r = fma_(-k, 4.837512969970703125e-4f, r);
+    r = fma_(-k, 7.54978995489188216e-8f, r);
+    int q = (int)k & 3;
+    float z = r * r;
+    float sp = fma_(z, fma_(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+    float s = fma_(r * z, sp, r);
+    float cp = fma_(z, fma_(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+    float c = fma_(z * z, cp, fma_(-0.5f, z, 1.0f));
+    float so = (q & 1) ? c : s;
+    float co = (q & 1) ? s : c;
+    if (q & 2) so = -so;
+    if ((q + 1) & 2) co = -co;
+    *s_out = so;
+    *c_out = co;
+}
+PT_DEV float sin_(float x) { float s, c; sincos_(x, &s, &c); return s; }
+PT_DEV float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
+
+PT_DEV float atan2_(float y, float x) {
+    float ax = abs_(x), ay = abs_(y);
+    float mx = fmax_(ax, ay), mn = fmin_(ax, ay);
+    if (mx == 0.0f) return 0.0f;
+    bool big = mn > 0.4142135623730950f * mx;
+    float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    float t = num / den;
+    float z = t * t;
+    float p = fma_(z, fma_(z, fma_(z, 8.05374449538e-2f, -1.38776856032e-1f), 1.99777106478e-1f), -3.33329491539e-1f);
+    float r = fma_(p * z, t, t);
+    if (big) r = DM_PIO4 + r;
+    if (ay > ax) r = DM_PIO2 - r;
+    if (x < 0.0f) r = DM_PI - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+PT_DEV float asin_poly(float z) {
+    return fma_(z, fma_(z, fma_(z, fma_(z, 4.2163199048e-2f, 2.4181311049e-2f), 4.5470025998e-2f), 7.4953002686e-2f), 1.6666752422e-1f);
+}
+PT_DEV float asin_(float x) {
+    float a = abs_(x);
+    bool big = a > 0.5f;
+    float z = big ? 0.5f * (1.0f - a) : a * a;
+    float s = big ? sqrt_(z) : a;
+    float r = fma_(s * z, asin_poly(z), s);
+    if (big) r = fma_(-2.0f, r, DM_PIO2);
+    return x < 0.0f ? -r : r;
+}
+PT_DEV float acos_(float x) {
+    float a = abs_(x);
+    if (a > 0.5f) {
+        float z = 0.5f * (1.0f - a);
+        float s = sqrt_(z);
+        float r = fma_(s * z, asin_poly(z), s);
+        r = r + r;
+        return x < 0.0f ? DM_PI - r : r;
+    }
+    float z = x * x;
+    float r = fma_(x * z, asin_poly(z), x);
+    return DM_PIO2 - r;
+}
+
+PT_DEV void log_core(float x, float* fe_out, float* lnm_out) {
+    int eadj = 0;
+    if (x < 1.17549435e-38f) { x = x * 8388608.0f; eadj = -23; }
+    uint32_t b = f2u(x);
+    int e = (int)((b >> 23) & 0xffu) - 126 + eadj;
+    float m = u2f((b & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+    float z = m * m;
+    float p = fma_(m, 7.0376836292e-2f, -1.1514610310e-1f);
+    p = fma_(p, m, 1.1676998740e-1f);
+    p = fma_(p, m, -1.2420140846e-1f);
+    p = fma_(p, m, 1.4249322787e-1f);
+    p = fma_(p, m, -1.6668057665e-1f);
+    p = fma_(p, m, 2.0000714765e-1f);
+    p = fma_(p, m, -2.4999993993e-1f);
+    p = fma_(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    y = fma_(-0.5f, z, y);
+    *fe_out = (float)e;
+    *lnm_out = m + y;
+}
+PT_DEV float log_(float x) {
+    if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+    if (x == __builtin_inff()) return x;
+    float fe, lnm;
+    log_core(x, &fe, &lnm);
+    float r = fma_(fe, -2.12194440e-4f, lnm);
+    return fma_(fe, 0.693359375f, r);
+}
+PT_DEV float log2_(float x) {
+    if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+    if (x == __builtin_inff()) return x;
+    float fe, lnm;
+    log_core(x, &fe, &lnm);
+    return fma_(lnm, 1.44269504088896341f, fe);
+}
+PT_DEV float exp2_(float x) {
+    if (x != x) return x;
+    if (x > 128.0f) return __builtin_inff();
+    if (x < -150.0f) return 0.0f;
+    float k = __builtin_rintf(x);
+    float f = x - k;
+    float p = fma_(f, 1.535336188319500e-4f, 1.339887440266574e-3f);
+    p = fma_(p, f, 9.618437357674640e-3f);
+    p = fma_(p, f, 5.550332471162809e-2f);
+    p = fma_(p, f, 2.402264791363012e-1f);
+    p = fma_(p, f, 6.931472028550421e-1f);
+    p = fma_(p, f, 1.0f);
+    int ki = (int)k;
+    int k1 = ki / 2, k2 = ki - k1;
+    float s1 = u2f((uint32_t)(k1 + 127) << 23);
+    float s2 = u2f((uint32_t)(k2 + 127) << 23);
+    return (p * s1) * s2;
+}
+PT_DEV float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+
+}  // namespace dm
+
+// ---- vector helpers: fixed expression trees ------------------------------------------------------
+// dot = fma chain from the low index; cross = fma(a,b,-(c*d)); madd = fma(d,t,o); everything else is
+// unfused and left to right.
+struct V2 { float x, y; };
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+PT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV V3 v3p(const float* p) { return v3(p[0], p[1], p[2]); }
+PT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+PT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+PT_DEV V3 operator/(V3 a, V3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+PT_DEV float dot(V3 a, V3 b) { return dm::fma_(a.z, b.z, dm::fma_(a.y, b.y, a.x * b.x)); }
+PT_DEV float dot2(float ax, float ay, float bx, float by) { return dm::fma_(ay, by, ax * bx); }
+PT_DEV float dot4(V4 a, V4 b) { return dm::fma_(a.w, b.w, dm::fma_(a.z, b.z, dm::fma_(a.y, b.y, a.x * b.x))); }
+PT_DEV V3 cross(V3 a, V3 b) {
+    return v3(dm::fma_(a.y, b.z, -(a.z * b.y)), dm::fma_(a.z, b.x, -(a.x * b.z)), dm::fma_(a.x, b.y, -(a.y * b.x)));
+}
+PT_DEV V3 madd(V3 o, V3 d, float t) { return v3(dm::fma_(d.x, t, o.x), dm::fma_(d.y, t, o.y), dm::fma_(d.z, t, o.z)); }
+PT_DEV float length(V3 a) { return dm::sqrt_(dot(a, a)); }
+PT_DEV V3 normalize(V3 a) { float inv = 1.0f / dm::sqrt_(dot(a, a)); return a * inv; }
+PT_DEV V3 vabs(V3 a) { return v3(dm::abs_(a.x), dm::abs_(a.y), dm::abs_(a.z)); }
+PT_DEV V3 vmin(V3 a, V3 b) { return v3(dm::fmin_(a.x, b.x), dm::fmin_(a.y, b.y), dm::fmin_(a.z, b.z)); }
+PT_DEV V3 vmax(V3 a, V3 b) { return v3(dm::fmax_(a.x, b.x), dm::fmax_(a.y, b.y), dm::fmax_(a.z, b.z)); }
+PT_DEV V3 vrcp(V3 a) { return v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
+PT_DEV float clampf(float x, float lo, float hi) { return dm::fmin_(dm::fmax_(x, lo), hi); }
+PT_DEV float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+PT_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+#define PT_PI 3.14159265359f
+#define PT_TWO_PI 6.28318530718f
+#define PT_INV_PI 0.31830988618f
+#define PT_EPS 0.0001f
+#define PT_MAX_T 1e20f

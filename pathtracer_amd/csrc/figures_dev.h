@@ -1,0 +1,771 @@
+// Ray / primitive intersection for the 17 figure types (reference: src/shaders/wgsl/figures/*.wgsl).
+//
+// Two passes instead of the reference's one: during traversal only the hit distance of each candidate
+// is computed (FULL = false); the winner alone is then resolved to position, normal and UV
+// (FULL = true, or finish_* for ray-marched figures, which reuse the marched distance).  The distance
+// is computed by the same instructions in both passes, so the split changes no result.
+#pragma once
+#include "dmath_dev.h"
+#include "dscene.h"
+
+struct Ray { V3 o, d; };
+struct HitFull { V3 pos, normal; V2 uv; };
+
+PT_DEV V2 sphere_uv(V3 d) {  // sphere.wgsl:34-37
+    V2 r;
+    r.x = 0.5f + dm::atan2_(d.z, d.x) / PT_TWO_PI;
+    r.y = 0.5f - dm::asin_(clampf(d.y, -1.0f, 1.0f)) / PT_PI;
+    return r;
+}
+struct Onb { V3 u, v, n; };
+PT_DEV Onb build_onb(V3 n) {  // utils.wgsl:6-13
+    float s = n.z >= 0.0f ? 1.0f : -1.0f;
+    float a = -1.0f / (s + n.z);
+    float b = n.x * n.y * a;
+    Onb o;
+    o.u = v3(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
+    o.v = v3(b, s + n.y * n.y * a, -n.y);
+    o.n = n;
+    return o;
+}
+PT_DEV V3 onb_mul(const Onb& o, V3 l) {
+    return v3(dm::fma_(o.n.x, l.z, dm::fma_(o.v.x, l.y, o.u.x * l.x)), dm::fma_(o.n.y, l.z, dm::fma_(o.v.y, l.y, o.u.y * l.x)),
+              dm::fma_(o.n.z, l.z, dm::fma_(o.v.z, l.y, o.u.z * l.x)));
+}
+
+template <bool FULL>
+PT_DEV bool isect_sphere(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // sphere.wgsl:4-40
+    V3 pos = v3p(g.p);
+    float radius = g.p[3];
+    V3 oc = ray.o - pos;
+    float half_b = dot(oc, ray.d);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = dm::fma_(half_b, half_b, -c);
+    if (disc < 0.0f) return false;
+    float sqrtd = dm::sqrt_(disc);
+    float t = -half_b - sqrtd;
+    if (t < PT_EPS) {
+        t = -half_b + sqrtd;
+        if (t < PT_EPS) return false;
+    }
+    t_out = t;
+    if (FULL) {
+        h->pos = madd(ray.o, ray.d, t);
+        h->normal = normalize(h->pos - pos);
+        if (need_uv) h->uv = sphere_uv(h->normal);
+    }
+    return true;
+}
+template <bool FULL>
+PT_DEV bool isect_plane(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // plane.wgsl:4-30
+    V3 pos = v3p(g.p), n = v3p(g.p + 3);
+    float denom = dot(n, ray.d);
+    if (dm::abs_(denom) < PT_EPS) return false;
+    float t = dot(pos - ray.o, n) / denom;
+    if (t < PT_EPS) return false;
+    t_out = t;
+    if (FULL) {
+        h->pos = madd(ray.o, ray.d, t);
+        h->normal = denom < 0.0f ? n : -n;
+        if (need_uv) {
+            Onb onb = build_onb(h->normal);
+            V3 local = h->pos - pos;
+            h->uv.x = dot(local, onb.u) * 0.25f;
+            h->uv.y = dot(local, onb.v) * 0.25f;
+        }
+    }
+    return true;
+}
+template <bool FULL>
+PT_DEV bool isect_cube(const Ray& ray, V3 inv_dir, const DPrim& g, float& t_out, HitFull* h) {  // cube.wgsl:4-60
+    V3 pos = v3p(g.p);
+    float r = g.p[3];
+    V3 half = v3(r, r, r);
+    V3 bmin = pos - half, bmax = pos + half;
+    V3 t1 = (bmin - ray.o) * inv_dir, t2 = (bmax - ray.o) * inv_dir;
+    V3 tmn = vmin(t1, t2), tmx = vmax(t1, t2);
+    float t_near = dm::fmax_(dm::fmax_(tmn.x, tmn.y), tmn.z);
+    float t_far = dm::fmin_(dm::fmin_(tmx.x, tmx.y), tmx.z);
+    if (t_near > t_far || t_far < PT_EPS) return false;
+    float t = t_near;
+    if (t < PT_EPS) {
+        t = t_far;
+        if (t < PT_EPS) return false;
+    }
+    t_out = t;
+    if (FULL) {
+        h->pos = madd(ray.o, ray.d, t);
+        V3 p = (h->pos - pos) / half;
+        V3 ap = vabs(p);
+        if (ap.x > ap.y && ap.x > ap.z) h->normal = v3(signf(p.x), 0.0f, 0.0f);
+        else if (ap.y > ap.z) h->normal = v3(0.0f, signf(p.y), 0.0f);
+        else h->normal = v3(0.0f, 0.0f, signf(p.z));
+        if (dm::abs_(h->normal.x) > 0.5f) { h->uv.x = (p.y + 1.0f) * 0.5f; h->uv.y = (p.z + 1.0f) * 0.5f; }
+        else if (dm::abs_(h->normal.y) > 0.5f) { h->uv.x = (p.x + 1.0f) * 0.5f; h->uv.y = (p.z + 1.0f) * 0.5f; }
+        else { h->uv.x = (p.x + 1.0f) * 0.5f; h->uv.y = (p.y + 1.0f) * 0.5f; }
+    }
+    return true;
+}
+template <bool FULL>
+PT_DEV bool isect_cylinder(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // cylinder.wgsl:4-69
+    V3 pos = v3p(g.p), axis = v3p(g.p + 3);
+    float radius = g.p[6], height = g.p[7];
+    float half_h = height * 0.5f;
+    V3 oc = ray.o - pos;
+    V3 d_perp = ray.d - axis * dot(ray.d, axis);
+    V3 oc_perp = oc - axis * dot(oc, axis);
+    float a = dot(d_perp, d_perp);
+    float half_b = dot(d_perp, oc_perp);
+    float c = dot(oc_perp, oc_perp) - radius * radius;
+    float disc = dm::fma_(half_b, half_b, -(a * c));
+    if (disc < 0.0f) return false;
+    float sqrtd = dm::sqrt_(disc);
+    float inv_a = 1.0f / a;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float t = i == 0 ? (-half_b - sqrtd) * inv_a : (-half_b + sqrtd) * inv_a;
+        if (t < PT_EPS) continue;
+        V3 p = madd(ray.o, ray.d, t);
+        float proj = dot(p - pos, axis);
+        if (dm::abs_(proj) <= half_h) {
+            t_out = t;
+            if (FULL) {
+                h->pos = p;
+                h->normal = normalize((p - pos) - axis * proj);
+                if (need_uv) {
+                    float angle = dm::atan2_(h->normal.z, h->normal.x);
+                    h->uv.x = angle / PT_TWO_PI + 0.5f;
+                    h->uv.y = (proj + half_h) / height;
+                }
+            }
+            return true;
+        }
+    }
+    bool hit = false;
+    float best = PT_MAX_T;
+    float d_axis = dot(ray.d, axis);
+    if (dm::abs_(d_axis) > PT_EPS) {
+#pragma unroll
+        for (int si = 0; si < 2; si++) {
+            float cap_sign = si == 1 ? -1.0f : 1.0f;
+            V3 cap_center = pos + axis * half_h * cap_sign;
+            float t = dot(cap_center - ray.o, axis * cap_sign) / (d_axis * cap_sign);
+            if (t > PT_EPS && t < best) {
+                V3 p = madd(ray.o, ray.d, t);
+                V3 off = p - cap_center;
+                if (dot(off, off) <= radius * radius) {
+                    hit = true;
+                    best = t;
+                    if (FULL) {
+                        h->pos = p;
+                        h->normal = axis * cap_sign;
+                        h->uv.x = (off.x / radius + 1.0f) * 0.5f;
+                        h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+                    }
+                }
+            }
+        }
+    }
+    t_out = best;
+    return hit;
+}
+template <bool FULL>
+PT_DEV bool isect_cone(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // cone.wgsl:4-80
+    V3 pos = v3p(g.p), axis = v3p(g.p + 3);
+    float radius = g.p[6], height = g.p[7], tan2 = g.p[8];
+    V3 apex = pos + axis * height;
+    V3 oc = ray.o - apex;
+    float d_dot_v = dot(ray.d, axis);
+    float oc_dot_v = dot(oc, axis);
+    float cos2 = 1.0f / (1.0f + tan2);
+    float a_c = dm::fma_(d_dot_v, d_dot_v, -(cos2 * dot(ray.d, ray.d)));
+    float b_c = dm::fma_(d_dot_v, oc_dot_v, -(cos2 * dot(ray.d, oc)));
+    float c_c = dm::fma_(oc_dot_v, oc_dot_v, -(cos2 * dot(oc, oc)));
+    float disc = dm::fma_(b_c, b_c, -(a_c * c_c));
+    if (disc < 0.0f) return false;
+    float sqrtd = dm::sqrt_(disc);
+    float inv_a = 1.0f / a_c;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float t = i == 0 ? (-b_c - sqrtd) * inv_a : (-b_c + sqrtd) * inv_a;
+        if (t < PT_EPS) continue;
+        V3 p = madd(ray.o, ray.d, t);
+        float proj = dot(p - apex, axis);
+        if (proj >= -height && proj <= 0.0f) {
+            t_out = t;
+            if (FULL) {
+                h->pos = p;
+                V3 to_p = normalize(p - apex);
+                float n_proj = dot(to_p, axis);
+                h->normal = normalize(to_p - axis * n_proj * (1.0f + tan2));
+                if (need_uv) {
+                    float angle = dm::atan2_(h->normal.z, h->normal.x);
+                    h->uv.x = angle / PT_TWO_PI + 0.5f;
+                    h->uv.y = -proj / height;
+                }
+            }
+            return true;
+        }
+    }
+    float d_axis2 = dot(ray.d, axis);
+    if (dm::abs_(d_axis2) > PT_EPS) {
+        float t = dot(pos - ray.o, axis) / d_axis2;
+        if (t > PT_EPS && t < PT_MAX_T) {
+            V3 p = madd(ray.o, ray.d, t);
+            V3 off = p - pos;
+            if (dot(off, off) <= radius * radius) {
+                t_out = t;
+                if (FULL) {
+                    h->pos = p;
+                    h->normal = -axis;
+                    h->uv.x = (off.x / radius + 1.0f) * 0.5f;
+                    h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+                }
+                return true;
+            }
+        }
+    }
+    return false;
+}
+template <bool FULL>
+PT_DEV bool isect_disc(const Ray& ray, const DPrim& g, float& t_out, HitFull* h) {  // disc.wgsl:4-35
+    V3 pos = v3p(g.p), n = v3p(g.p + 3);
+    float radius = g.p[6];
+    float denom = dot(n, ray.d);
+    if (dm::abs_(denom) < PT_EPS) return false;
+    float t = dot(pos - ray.o, n) / denom;
+    if (t < PT_EPS) return false;
+    V3 p = madd(ray.o, ray.d, t);
+    V3 off = p - pos;
+    if (dot(off, off) > radius * radius) return false;
+    t_out = t;
+    if (FULL) {
+        h->pos = p;
+        h->normal = denom < 0.0f ? n : -n;
+        h->uv.x = (off.x / radius + 1.0f) * 0.5f;
+        h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+    }
+    return true;
+}
+// Moller-Trumbore core of triangle.wgsl:9-36, pyramid.wgsl:38-61, tetrahedron.wgsl:36-59.
+PT_DEV bool mt_core(const Ray& ray, V3 v0, V3 e1, V3 e2, float& t, float& u, float& v) {
+    V3 hh = cross(ray.d, e2);
+    float a = dot(e1, hh);
+    if (dm::abs_(a) < PT_EPS) return false;
+    float fi = 1.0f / a;
+    V3 s = ray.o - v0;
+    u = fi * dot(s, hh);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = cross(s, e1);
+    v = fi * dot(ray.d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = fi * dot(e2, q);
+    return true;
+}
+PT_DEV float half_to_float(uint32_t hb) {  // WGSL unpack2x16float, exact
+    uint32_t sign = (hb & 0x8000u) << 16, e = (hb >> 10) & 0x1Fu, m = hb & 0x3FFu;
+    if (e == 0u) {
+        if (m == 0u) return dm::u2f(sign);
+        float v = (float)m * 5.9604644775390625e-8f;
+        return sign ? -v : v;
+    }
+    if (e == 31u) return dm::u2f(sign | 0x7F800000u | (m << 13));
+    return dm::u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+template <bool FULL>
+PT_DEV bool isect_triangle(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv, const DShade* sh) {  // triangle.wgsl:4-53
+    V3 v0 = v3p(g.p), e1 = v3p(g.p + 3), e2 = v3p(g.p + 6);
+    float t, u, v;
+    if (!mt_core(ray, v0, e1, e2, t, u, v)) return false;
+    if (t < PT_EPS) return false;
+    t_out = t;
+    if (FULL) {
+        h->pos = madd(ray.o, ray.d, t);
+        h->normal = normalize(cross(e1, e2));
+        if (dot(h->normal, ray.d) > 0.0f) h->normal = -h->normal;
+        if (need_uv) {
+            uint32_t a = sh->uv0, b = sh->uv1, c = sh->uv2;
+            float w0 = 1.0f - u - v;
+            h->uv.x = dm::fma_(v, half_to_float(c & 0xFFFFu), dm::fma_(u, half_to_float(b & 0xFFFFu), w0 * half_to_float(a & 0xFFFFu)));
+            h->uv.y = dm::fma_(v, half_to_float(c >> 16), dm::fma_(u, half_to_float(b >> 16), w0 * half_to_float(a >> 16)));
+        }
+    }
+    return true;
+}
+// Keep-closest face test of pyramid.wgsl:35-70 / tetrahedron.wgsl:33-68 (normal not ray-facing, uv = (u,v)).
+template <bool FULL>
+PT_DEV void face_test(const Ray& ray, V3 v0, V3 v1, V3 v2, bool& hit, float& best, HitFull* h) {
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    float t, u, v;
+    if (!mt_core(ray, v0, e1, e2, t, u, v)) return;
+    if (t > PT_EPS && t < best) {
+        hit = true;
+        best = t;
+        if (FULL) {
+            h->pos = madd(ray.o, ray.d, t);
+            h->normal = normalize(cross(e1, e2));
+            h->uv.x = u;
+            h->uv.y = v;
+        }
+    }
+}
+template <bool FULL>
+PT_DEV bool isect_pyramid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h) {  // pyramid.wgsl:5-32
+    V3 base = v3p(g.p);
+    float r = g.p[3], hh = g.p[4];
+    V3 apex = base + v3(0.0f, hh, 0.0f);
+    V3 b0 = base + v3(-r, 0.0f, -r), b1 = base + v3(r, 0.0f, -r), b2 = base + v3(r, 0.0f, r), b3 = base + v3(-r, 0.0f, r);
+    bool hit = false;
+    float best = PT_MAX_T;
+    face_test<FULL>(ray, apex, b0, b1, hit, best, h);
+    face_test<FULL>(ray, apex, b1, b2, hit, best, h);
+    face_test<FULL>(ray, apex, b2, b3, hit, best, h);
+    face_test<FULL>(ray, apex, b3, b0, hit, best, h);
+    face_test<FULL>(ray, b0, b2, b1, hit, best, h);
+    face_test<FULL>(ray, b0, b3, b2, hit, best, h);
+    t_out = best;
+    return hit;
+}
+template <bool FULL>
+PT_DEV bool isect_tetrahedron(const Ray& ray, const DPrim& g, float& t_out, HitFull* h) {  // tetrahedron.wgsl:4-31
+    V3 pos = v3p(g.p);
+    float r = g.p[3];
+    float a = r * 0.942809f, b = r * 0.333333f, c = r * 0.816497f;
+    V3 v0 = pos + v3(0.0f, r, 0.0f);
+    V3 v1 = pos + v3(a, -b, -c * 0.5f);
+    V3 v2 = pos + v3(-a, -b, -c * 0.5f);
+    V3 v3_ = pos + v3(0.0f, -b, c);
+    bool hit = false;
+    float best = PT_MAX_T;
+    face_test<FULL>(ray, v0, v1, v2, hit, best, h);
+    face_test<FULL>(ray, v0, v2, v3_, hit, best, h);
+    face_test<FULL>(ray, v0, v3_, v1, hit, best, h);
+    face_test<FULL>(ray, v1, v3_, v2, hit, best, h);
+    t_out = best;
+    return hit;
+}
+template <bool FULL>
+PT_DEV bool isect_ellipsoid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // ellipsoid.wgsl:5-52
+    V3 pos = v3p(g.p);
+    float radius = g.p[3], height = g.p[4], radius2 = g.p[5];
+    V3 radii = v3(radius, dm::fmax_(height, radius), dm::fmax_(radius2, radius));
+    V3 inv_radii = vrcp(radii);
+    V3 oc = (ray.o - pos) * inv_radii;
+    V3 dir = ray.d * inv_radii;
+    float a = dot(dir, dir);
+    float half_b = dot(oc, dir);
+    float c = dot(oc, oc) - 1.0f;
+    float disc = dm::fma_(half_b, half_b, -(a * c));
+    if (disc < 0.0f) return false;
+    float sqrtd = dm::sqrt_(disc);
+    float inv_a = 1.0f / a;
+    float t = (-half_b - sqrtd) * inv_a;
+    if (t < PT_EPS) {
+        t = (-half_b + sqrtd) * inv_a;
+        if (t < PT_EPS) return false;
+    }
+    t_out = t;
+    if (FULL) {
+        h->pos = madd(ray.o, ray.d, t);
+        V3 local = h->pos - pos;
+        h->normal = normalize(local * inv_radii * inv_radii);
+        if (need_uv) h->uv = sphere_uv(normalize(local * inv_radii));
+    }
+    return true;
+}
+template <bool FULL>
+PT_DEV bool isect_paraboloid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // paraboloid.wgsl:4-67
+    V3 pos = v3p(g.p);
+    float r = g.p[3], hh = g.p[4];
+    V3 oc = ray.o - pos, d = ray.d;
+    float a = dot2(d.x, d.z, d.x, d.z);
+    float b = 2.0f * dot2(oc.x, oc.z, d.x, d.z) - r * d.y;
+    float c = dot2(oc.x, oc.z, oc.x, oc.z) - r * oc.y;
+    float disc = dm::fma_(b, b, -(4.0f * a * c));
+    if (disc < 0.0f) return false;
+    float sqrtd = dm::sqrt_(disc);
+    float inv_2a = 0.5f / a;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float t = i == 0 ? (-b - sqrtd) * inv_2a : (-b + sqrtd) * inv_2a;
+        if (t < PT_EPS) continue;
+        V3 p = madd(ray.o, d, t);
+        float local_y = p.y - pos.y;
+        if (local_y >= 0.0f && local_y <= hh) {
+            t_out = t;
+            if (FULL) {
+                h->pos = p;
+                V3 local = p - pos;
+                h->normal = normalize(v3(2.0f * local.x, -r, 2.0f * local.z));
+                if (need_uv) {
+                    float angle = dm::atan2_(local.z, local.x);
+                    h->uv.x = angle / PT_TWO_PI + 0.5f;
+                    h->uv.y = local_y / hh;
+                }
+            }
+            return true;
+        }
+    }
+    float d_y = d.y;
+    if (dm::abs_(d_y) > PT_EPS) {
+        float cap_y = pos.y + hh;
+        float t = (cap_y - ray.o.y) / d_y;
+        if (t > PT_EPS) {
+            V3 p = madd(ray.o, d, t);
+            V3 local = p - pos;
+            float dist2 = dot2(local.x, local.z, local.x, local.z);
+            if (dist2 <= r * hh) {
+                t_out = t;
+                if (FULL) {
+                    h->pos = p;
+                    h->normal = v3(0.0f, 1.0f, 0.0f);
+                    float s = dm::sqrt_(r * hh);
+                    h->uv.x = local.x / s * 0.5f + 0.5f;
+                    h->uv.y = local.z / s * 0.5f + 0.5f;
+                }
+                return true;
+            }
+        }
+    }
+    return false;
+}
+template <bool FULL>
+PT_DEV bool isect_hyperboloid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // hyperboloid.wgsl:4-68
+    V3 pos = v3p(g.p);
+    float r = g.p[3], height = g.p[4];
+    V3 oc = ray.o - pos, d = ray.d;
+    float half_h = height * 0.5f;
+    float inv_r2 = 1.0f / (r * r);
+    float a = (dot2(d.x, d.z, d.x, d.z) - d.y * d.y) * inv_r2;
+    float b = 2.0f * (dot2(oc.x, oc.z, d.x, d.z) - oc.y * d.y) * inv_r2;
+    float c = (dot2(oc.x, oc.z, oc.x, oc.z) - oc.y * oc.y) * inv_r2 - 1.0f;
+    float disc = dm::fma_(b, b, -(4.0f * a * c));
+    bool hit = false;
+    float best = PT_MAX_T;
+    if (disc >= 0.0f) {
+        float sqrtd = dm::sqrt_(disc);
+        float inv_2a = 0.5f / a;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float t = i == 0 ? (-b - sqrtd) * inv_2a : (-b + sqrtd) * inv_2a;
+            if (t < PT_EPS || t >= best) continue;
+            V3 p = madd(ray.o, d, t);
+            float local_y = p.y - pos.y;
+            if (dm::abs_(local_y) <= half_h) {
+                hit = true;
+                best = t;
+                if (FULL) {
+                    h->pos = p;
+                    V3 local = p - pos;
+                    h->normal = normalize(v3(2.0f * local.x, -2.0f * local.y, 2.0f * local.z) * inv_r2);
+                    if (need_uv) {
+                        float angle = dm::atan2_(local.z, local.x);
+                        h->uv.x = angle / PT_TWO_PI + 0.5f;
+                        h->uv.y = (local_y + half_h) / height;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int cap = 0; cap < 2; cap++) {
+        float cap_y = pos.y + (cap == 1 ? half_h : -half_h);
+        if (dm::abs_(d.y) > PT_EPS) {
+            float t = (cap_y - ray.o.y) / d.y;
+            if (t > PT_EPS && t < best) {
+                V3 p = madd(ray.o, d, t);
+                V3 local = p - pos;
+                float dist2 = dot2(local.x, local.z, local.x, local.z);
+                float cap_r2 = r * r * (1.0f + (half_h * half_h) * inv_r2);
+                if (dist2 <= cap_r2) {
+                    hit = true;
+                    best = t;
+                    if (FULL) {
+                        h->pos = p;
+                        h->normal = cap == 1 ? v3(0.0f, 1.0f, 0.0f) : v3(0.0f, -1.0f, 0.0f);
+                        float s = dm::sqrt_(cap_r2);
+                        h->uv.x = local.x / s * 0.5f + 0.5f;
+                        h->uv.y = local.z / s * 0.5f + 0.5f;
+                    }
+                }
+            }
+        }
+    }
+    t_out = best;
+    return hit;
+}
+template <bool FULL>
+PT_DEV bool isect_skybox(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // skybox.wgsl:30-62
+    V3 pos = v3p(g.p);
+    float radius = g.p[3];
+    V3 oc = ray.o - pos;
+    float half_b = dot(oc, ray.d);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = dm::fma_(half_b, half_b, -c);
+    if (disc < 0.0f) return false;
+    float t = -half_b + dm::sqrt_(disc);
+    if (t < PT_EPS) return false;
+    t_out = t;
+    if (FULL) {
+        h->pos = madd(ray.o, ray.d, t);
+        V3 d = normalize(h->pos - pos);
+        h->normal = -d;
+        if (need_uv) h->uv = sphere_uv(d);
+    }
+    return true;
+}
+
+// ---- ray-marched figures -------------------------------------------------------------------------
+PT_DEV float sdf_torus(V3 p, float major_r, float minor_r) {  // torus.wgsl:5-8
+    float qx = dm::sqrt_(dot2(p.x, p.z, p.x, p.z)) - major_r;
+    return dm::sqrt_(dot2(qx, p.y, qx, p.y)) - minor_r;
+}
+PT_DEV float sdf_mebius(V3 p, float R) {  // mebius.wgsl:5-36
+    float w = R * 0.3f;
+    float angle = dm::atan2_(p.z, p.x);
+    float sa, ca;
+    dm::sincos_(angle, &sa, &ca);
+    V3 center = v3(R * ca, 0.0f, R * sa);
+    V3 radial = normalize(v3(ca, 0.0f, sa));
+    float sh, ch;
+    dm::sincos_(angle * 0.5f, &sh, &ch);
+    V3 strip_up = v3(0.0f, 1.0f, 0.0f) * ch + radial * sh;
+    V3 dp = p - center;
+    float v = dot(dp, strip_up);
+    float u = length(dp - strip_up * v);
+    float du = dm::abs_(u) - w * 0.15f;
+    float dv = dm::abs_(v) - w;
+    float mx = dm::fmax_(du, 0.0f), my = dm::fmax_(dv, 0.0f);
+    return dm::sqrt_(dot2(mx, my, mx, my)) + dm::fmin_(dm::fmax_(du, dv), 0.0f);
+}
+PT_DEV float sdf_mandelbulb(V3 p, float power, int max_iter) {  // mandelbulb.wgsl:5-30
+    V3 w = p;
+    float m = dot(w, w);
+    float dz = 1.0f;
+    for (int i = 0; i < max_iter; i++) {
+        dz = dm::fma_(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
+        float r = dm::sqrt_(m);
+        float b = power * dm::acos_(clampf(w.y / r, -1.0f, 1.0f));
+        float a = power * dm::atan2_(w.x, w.z);
+        float rp = dm::pow_(r, power);
+        float sb, cb, sa, ca;
+        dm::sincos_(b, &sb, &cb);
+        dm::sincos_(a, &sa, &ca);
+        w = p + v3(sb * sa, cb, sb * ca) * rp;
+        m = dot(w, w);
+        if (m > 256.0f) break;
+    }
+    float r = dm::sqrt_(m);
+    return 0.25f * dm::log_(m) * r / dz;
+}
+PT_DEV V4 quat_mult(V4 a, V4 b) {  // julia.wgsl:4-11
+    V4 r;
+    r.x = a.x * b.x - a.y * b.y - a.z * b.z - a.w * b.w;
+    r.y = a.x * b.y + a.y * b.x + a.z * b.w - a.w * b.z;
+    r.z = a.x * b.z - a.y * b.w + a.z * b.x + a.w * b.y;
+    r.w = a.x * b.w + a.y * b.z - a.z * b.y + a.w * b.x;
+    return r;
+}
+PT_DEV float sdf_julia(V3 p, V4 cc, int max_iter) {  // julia.wgsl:13-32
+    V4 z; z.x = p.x; z.y = p.y; z.z = p.z; z.w = 0.0f;
+    V4 dz; dz.x = 1.0f; dz.y = 0.0f; dz.z = 0.0f; dz.w = 0.0f;
+    float r2 = dot4(z, z);
+    for (int i = 0; i < max_iter; i++) {
+        if (r2 > 16.0f) break;
+        V4 q = quat_mult(z, dz);
+        dz.x = 2.0f * q.x; dz.y = 2.0f * q.y; dz.z = 2.0f * q.z; dz.w = 2.0f * q.w;
+        V4 zz = quat_mult(z, z);
+        z.x = zz.x + cc.x; z.y = zz.y + cc.y; z.z = zz.z + cc.z; z.w = zz.w + cc.w;
+        r2 = dot4(z, z);
+    }
+    float r = dm::sqrt_(r2);
+    float dr = dm::sqrt_(dot4(dz, dz));
+    return 0.5f * r * dm::log_(r) / dr;
+}
+
+// Evaluates the figure's distance field at a point given in the space its marcher steps in.
+PT_DEV float sdf_eval(const DPrim& g, V3 p) {
+    switch (g.type) {
+        case FIG_TORUS: return sdf_torus(p, g.p[3], g.p[4]);
+        case FIG_MEBIUS: return sdf_mebius(p, g.p[3]);
+        case FIG_MANDELBULB: return sdf_mandelbulb(p, g.p[4], (int)g.p[5]);
+        default: { V4 c; c.x = g.p[5]; c.y = g.p[6]; c.z = g.p[7]; c.w = g.p[8]; return sdf_julia(p, c, (int)g.p[4]); }
+    }
+}
+// Tetrahedron normal: offsets e.xyy, e.yyx, e.yxy, e.xxx with e = (k, -k)  (torus.wgsl:54-61 etc.)
+PT_DEV V3 tet_normal(const DPrim& g, V3 local, float k) {
+    V3 o0 = v3(k, -k, -k), o1 = v3(-k, -k, k), o2 = v3(-k, k, -k), o3 = v3(k, k, k);
+    float d0 = sdf_eval(g, local + o0), d1 = sdf_eval(g, local + o1), d2 = sdf_eval(g, local + o2), d3 = sdf_eval(g, local + o3);
+    return normalize(o0 * d0 + o1 * d1 + o2 * d2 + o3 * d3);
+}
+// torus.wgsl:10-81
+PT_DEV bool march_torus(const Ray& ray, const DPrim& g, float& t_out) {
+    float major_r = g.p[3], minor_r = g.p[4];
+    float bound_r = major_r + minor_r;
+    V3 pos = v3p(g.p);
+    V3 oc = ray.o - pos;
+    float b = dot(oc, ray.d);
+    float br = bound_r + minor_r;
+    float cc = dot(oc, oc) - br * br;
+    float disc = dm::fma_(b, b, -cc);
+    if (disc < 0.0f) return false;
+    const float omega = 1.4f;
+    float sq = dm::sqrt_(dm::fmax_(disc, 0.0f));
+    float t = dm::fmax_(-b - sq, PT_EPS);
+    float max_t = dm::fmin_(-b + sq, PT_MAX_T);
+    float prev_d = 0.0f;
+    for (int i = 0; i < 128; i++) {
+        V3 p = madd(ray.o, ray.d, t) - pos;
+        float d = sdf_torus(p, major_r, minor_r);
+        if (d < 0.0f && prev_d > 0.0f) {
+            t -= prev_d * (omega - 1.0f);
+            V3 p2 = madd(ray.o, ray.d, t) - pos;
+            float d2 = sdf_torus(p2, major_r, minor_r);
+            t += d2;
+            prev_d = d2;
+            continue;
+        }
+        if (dm::abs_(d) < PT_EPS * t) { t_out = t; return true; }
+        t += d * omega;
+        prev_d = d;
+        if (t > max_t) break;
+    }
+    return false;
+}
+PT_DEV void finish_torus(const Ray& ray, const DPrim& g, float t, HitFull* h, bool need_uv) {
+    V3 pos = v3p(g.p);
+    h->pos = madd(ray.o, ray.d, t);
+    V3 local = h->pos - pos;
+    h->normal = tet_normal(g, local, 0.5773f * PT_EPS);
+    if (need_uv) {
+        float angle_major = dm::atan2_(local.z, local.x);
+        float px = dm::sqrt_(dot2(local.x, local.z, local.x, local.z)) - g.p[3];
+        float angle_minor = dm::atan2_(local.y, px);
+        h->uv.x = angle_major / PT_TWO_PI + 0.5f;
+        h->uv.y = angle_minor / PT_TWO_PI + 0.5f;
+    }
+}
+// mebius.wgsl:38-87
+PT_DEV bool march_mebius(const Ray& ray, const DPrim& g, float& t_out) {
+    V3 pos = v3p(g.p);
+    float R = g.p[3];
+    V3 oc = ray.o - pos;
+    float b = dot(oc, ray.d);
+    float bound_r = R * 1.5f;
+    float cc = dot(oc, oc) - bound_r * bound_r;
+    float disc = dm::fma_(b, b, -cc);
+    if (disc < 0.0f) return false;
+    float sq = dm::sqrt_(disc);
+    float t = dm::fmax_(-b - sq, PT_EPS);
+    float max_t = -b + sq;
+    for (int i = 0; i < 256; i++) {
+        V3 p = madd(ray.o, ray.d, t) - pos;
+        float d = sdf_mebius(p, R);
+        if (dm::abs_(d) < PT_EPS * t * 0.5f) { t_out = t; return true; }
+        t += d;
+        if (t > max_t) break;
+    }
+    return false;
+}
+PT_DEV void finish_mebius(const Ray& ray, const DPrim& g, float t, HitFull* h, bool need_uv) {
+    V3 pos = v3p(g.p);
+    h->pos = madd(ray.o, ray.d, t);
+    V3 local = h->pos - pos;
+    h->normal = tet_normal(g, local, 0.5773f * PT_EPS * 2.0f);
+    if (need_uv) {
+        float angle = dm::atan2_(local.z, local.x);
+        h->uv.x = angle / PT_TWO_PI + 0.5f;
+        h->uv.y = 0.5f;
+    }
+}
+// mandelbulb.wgsl:32-101 / julia.wgsl:34-101
+PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, float& t_out) {
+    V3 pos = v3p(g.p);
+    float radius = g.p[3];
+    V3 oc = ray.o - pos;
+    float b = dot(oc, ray.d);
+    float bound_r = radius * 1.5f;
+    float cs = dot(oc, oc) - bound_r * bound_r;
+    float disc = dm::fma_(b, b, -cs);
+    if (disc < 0.0f) return false;
+    const float omega = 1.3f;
+    float sq = dm::sqrt_(disc);
+    float t = dm::fmax_(-b - sq, PT_EPS);
+    float max_t = -b + sq;
+    float prev_d = 0.0f;
+    for (uint32_t i = 0; i < march_steps; i++) {
+        V3 p = madd(ray.o, ray.d, t) - pos;
+        float d = sdf_eval(g, p / radius) * radius;
+        if (d < 0.0f && prev_d > 0.0f) {
+            t -= prev_d * (omega - 1.0f);
+            V3 p2 = madd(ray.o, ray.d, t) - pos;
+            float d2 = sdf_eval(g, p2 / radius) * radius;
+            t += d2;
+            prev_d = d2;
+            continue;
+        }
+        if (dm::abs_(d) < PT_EPS * t * 0.5f) { t_out = t; return true; }
+        t += d * omega;
+        prev_d = d;
+        if (t > max_t) break;
+    }
+    return false;
+}
+PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) {
+    V3 pos = v3p(g.p);
+    h->pos = madd(ray.o, ray.d, t);
+    V3 local = (h->pos - pos) / g.p[3];
+    h->normal = tet_normal(g, local, 0.5773f * PT_EPS * 2.0f);
+    h->uv.x = 0.0f;
+    h->uv.y = 0.0f;
+}
+
+// Candidate test: hit distance only (figures/dispatch.wgsl:22-89).
+PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t march_steps, float& t) {
+    switch (g.type) {
+        case FIG_SPHERE: return isect_sphere<false>(ray, g, t, nullptr, false);
+        case FIG_PLANE: return isect_plane<false>(ray, g, t, nullptr, false);
+        case FIG_CUBE: return isect_cube<false>(ray, inv_dir, g, t, nullptr);
+        case FIG_CYLINDER: return isect_cylinder<false>(ray, g, t, nullptr, false);
+        case FIG_CONE: return isect_cone<false>(ray, g, t, nullptr, false);
+        case FIG_TORUS: return march_torus(ray, g, t);
+        case FIG_DISC: return isect_disc<false>(ray, g, t, nullptr);
+        case FIG_TRIANGLE: return isect_triangle<false>(ray, g, t, nullptr, false, nullptr);
+        case FIG_SKYBOX: return isect_skybox<false>(ray, g, t, nullptr, false);
+        case FIG_MANDELBULB:
+        case FIG_JULIA: return march_fractal(ray, g, march_steps, t);
+        case FIG_ELLIPSOID: return isect_ellipsoid<false>(ray, g, t, nullptr, false);
+        case FIG_PARABOLOID: return isect_paraboloid<false>(ray, g, t, nullptr, false);
+        case FIG_HYPERBOLOID: return isect_hyperboloid<false>(ray, g, t, nullptr, false);
+        case FIG_MEBIUS: return march_mebius(ray, g, t);
+        case FIG_PYRAMID: return isect_pyramid<false>(ray, g, t, nullptr);
+        case FIG_TETRAHEDRON: return isect_tetrahedron<false>(ray, g, t, nullptr);
+        default: return false;
+    }
+}
+// Winner resolution: position, normal and (when the material is textured) UV of the hit at distance t.
+PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, bool need_uv, const DShade* sh, HitFull* h) {
+    float tt;
+    h->uv.x = 0.0f;
+    h->uv.y = 0.0f;
+    switch (g.type) {
+        case FIG_SPHERE: isect_sphere<true>(ray, g, tt, h, need_uv); break;
+        case FIG_PLANE: isect_plane<true>(ray, g, tt, h, need_uv); break;
+        case FIG_CUBE: isect_cube<true>(ray, inv_dir, g, tt, h); break;
+        case FIG_CYLINDER: isect_cylinder<true>(ray, g, tt, h, need_uv); break;
+        case FIG_CONE: isect_cone<true>(ray, g, tt, h, need_uv); break;
+        case FIG_TORUS: finish_torus(ray, g, t, h, need_uv); break;
+        case FIG_DISC: isect_disc<true>(ray, g, tt, h); break;
+        case FIG_TRIANGLE: isect_triangle<true>(ray, g, tt, h, need_uv, sh); break;
+        case FIG_SKYBOX: isect_skybox<true>(ray, g, tt, h, need_uv); break;
+        case FIG_MANDELBULB:
+        case FIG_JULIA: finish_fractal(ray, g, t, h); break;
+        case FIG_ELLIPSOID: isect_ellipsoid<true>(ray, g, tt, h, need_uv); break;
+        case FIG_PARABOLOID: isect_paraboloid<true>(ray, g, tt, h, need_uv); break;
+        case FIG_HYPERBOLOID: isect_hyperboloid<true>(ray, g, tt, h, need_uv); break;
+        case FIG_MEBIUS: finish_mebius(ray, g, t, h, need_uv); break;
+        case FIG_PYRAMID: isect_pyramid<true>(ray, g, tt, h); break;
+        case FIG_TETRAHEDRON: isect_tetrahedron<true>(ray, g, tt, h); break;
+        default: h->pos = madd(ray.o, ray.d, t); h->normal = v3(0.0f, 0.0f, 0.0f); break;
+    }
+}

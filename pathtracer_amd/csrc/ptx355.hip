@@ -1,0 +1,746 @@
+// ptx355: kernels and the C ABI (include/ptx355.h) of the MI355X path-tracing compute pass.
+//
+// Execution model.  One lane owns one pixel for the whole launch and walks a flattened state machine:
+// each loop iteration is ONE bounce of the lane's current sample; when a path ends the lane folds the
+// sample into its running mean (kept in registers) and immediately regenerates the camera ray of its
+// next sample.  A wave therefore stays full until its lanes run out of samples, instead of idling
+// behind the longest path of every sample as a one-sample-per-dispatch kernel does; with n samples per
+// launch the accumulation buffer is read and written once instead of n times.  A wave covers an 8x8
+// pixel block (primary rays stay coherent), a 256-thread workgroup a 16x16 block, and workgroups are
+// dealt so that each XCD's L2 serves one contiguous band of the frame.  Traversal stacks live in LDS
+// (lane-interleaved 8-byte entries, conflict-free); scene data is re-laid-out at upload into 64-byte
+// records (dscene.h).  No MFMA: nothing here is a dense contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "trace_dev.h"
+
+#define PTX_BLOCK 256
+#define PTX_WAVES_PER_BLOCK 4
+
+struct TraceParams {
+    DScene sc;
+    ptx_camera cam;
+    uint32_t first_frame, first_sample, n;
+    uint32_t tile_x0, tile_y0, tile_w, tile_h;
+    uint32_t blocks_x, n_blocks;
+    float4* accum;
+    uint32_t* out_rgba8;
+    uint32_t* primary_ids;
+    float* m2;            // null unless moments are enabled
+    float* dbg_radiance;  // null unless capture is enabled
+    uint32_t dbg_capacity;
+    unsigned long long* stats;  // paths, bounces, shadow rays
+};
+
+// Bijective block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so give the
+// blocks of one XCD a contiguous range of logical tile indices.
+PT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    uint32_t q = n / 8u, r = n % 8u, x = b % 8u;
+    uint32_t base = x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q;
+    return base + b / 8u;
+}
+
+PT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_trace_kernel(const TraceParams P) {
+    extern __shared__ StackEntry lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    StackEntry* st = lds_stack + (size_t)wave * P.sc.stack_entries * 64u + lane;
+
+    const uint32_t blk = xcd_remap(blockIdx.x, P.n_blocks);
+    const uint32_t bx = blk % P.blocks_x, by = blk / P.blocks_x;
+    const uint32_t tx = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ty = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const bool inside = tx < P.tile_w && ty < P.tile_h;
+    const uint32_t px = P.tile_x0 + tx, py = P.tile_y0 + ty;
+    const size_t pix = (size_t)py * P.cam.width + px;
+
+    V3 mean = v3(0.0f, 0.0f, 0.0f), m2 = v3(0.0f, 0.0f, 0.0f);
+    bool active = inside && P.n > 0u;
+    if (active) {
+        float4 a = P.accum[pix];
+        mean = v3(a.x, a.y, a.z);
+        if (P.m2) m2 = v3(P.m2[pix * 3], P.m2[pix * 3 + 1], P.m2[pix * 3 + 2]);
+    }
+    uint32_t k = 0, n_bounce = 0, n_shadow = 0, primary = 0xFFFFFFFFu;
+    PathState ps;
+    ps.rng = 0u;
+    ps.bounce = 0u;
+    ps.throughput = v3(1.0f, 1.0f, 1.0f);
+    ps.radiance = v3(0.0f, 0.0f, 0.0f);
+    ps.ray.o = v3(0.0f, 0.0f, 0.0f);
+    ps.ray.d = v3(0.0f, 0.0f, 1.0f);
+    if (active) {
+        ps.rng = pcg_hash(px + py * 65536u + P.first_frame * 16777259u);  // random.wgsl:12-14
+        ps.ray = generate_ray(P.cam, ps.rng, (float)px, (float)py);
+    }
+    while (active) {
+        bool done = true;
+        if (ps.bounce < P.cam.max_bounces) {
+            uint32_t fig;
+            n_bounce += 1u;
+            const bool first = ps.bounce == 0u;
+            done = bounce_step(P.sc, P.cam, ps, st, fig, n_shadow);
+            if (first) primary = fig;
+            if (!done && ps.bounce >= P.cam.max_bounces) done = true;
+        }
+        if (done) {
+            // path_trace.wgsl:181 and :44-49
+            V3 rad = v3(dm::fmax_(ps.radiance.x, 0.0f), dm::fmax_(ps.radiance.y, 0.0f), dm::fmax_(ps.radiance.z, 0.0f));
+            float nn = dm::fmax_((float)(P.first_sample + k), 1.0f);
+            V3 delta = rad - mean;
+            V3 nm = mean + delta / nn;
+            if (P.m2) {
+                V3 d2 = rad - nm;
+                m2 = v3(dm::fma_(delta.x, d2.x, m2.x), dm::fma_(delta.y, d2.y, m2.y), dm::fma_(delta.z, d2.z, m2.z));
+            }
+            mean = nm;
+            if (P.dbg_radiance && k < P.dbg_capacity) {
+                size_t r = ((size_t)k * P.tile_h * P.tile_w + (size_t)ty * P.tile_w + tx) * 3;
+                P.dbg_radiance[r] = rad.x;
+                P.dbg_radiance[r + 1] = rad.y;
+                P.dbg_radiance[r + 2] = rad.z;
+            }
+            k += 1u;
+            if (k < P.n) {
+                ps.rng = pcg_hash(px + py * 65536u + (P.first_frame + k) * 16777259u);
+                ps.ray = generate_ray(P.cam, ps.rng, (float)px, (float)py);
+                ps.throughput = v3(1.0f, 1.0f, 1.0f);
+                ps.radiance = v3(0.0f, 0.0f, 0.0f);
+                ps.bounce = 0u;
+            } else {
+                active = false;
+            }
+        }
+    }
+    if (inside && P.n > 0u) {
+        P.accum[pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+        if (P.m2) { P.m2[pix * 3] = m2.x; P.m2[pix * 3 + 1] = m2.y; P.m2[pix * 3 + 2] = m2.z; }
+        P.out_rgba8[pix] = tonemap_rgba8(P.cam, mean);
+        P.primary_ids[pix] = primary;
+    }
+    uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow), sp = wave_sum(k);
+    if (lane == 0u && P.stats) {
+        atomicAdd(&P.stats[0], (unsigned long long)sp);
+        atomicAdd(&P.stats[1], (unsigned long long)sb);
+        atomicAdd(&P.stats[2], (unsigned long long)ss);
+    }
+}
+
+// Chan's parallel update of (mean, M2) with another partial result, then re-tonemap.
+extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* out_rgba8, uint32_t first, uint32_t n_pixels,
+                                            float n_a, const float4* o_mean, const float* o_m2, float n_b, const ptx_camera cam) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    size_t p = (size_t)first + i;
+    float4 a = accum[p], b = o_mean[i];
+    float n = n_a + n_b;
+    float wb = n_b / n, wab = n_a * n_b / n;
+    V3 ma = v3(a.x, a.y, a.z), mb = v3(b.x, b.y, b.z);
+    V3 d = mb - ma;
+    V3 m = ma + d * wb;
+    if (n_a == 0.0f) m = mb;  // an untouched accumulator contributes nothing
+    if (m2 && o_m2) {
+        m2[p * 3] = m2[p * 3] + o_m2[(size_t)i * 3] + d.x * d.x * wab;
+        m2[p * 3 + 1] = m2[p * 3 + 1] + o_m2[(size_t)i * 3 + 1] + d.y * d.y * wab;
+        m2[p * 3 + 2] = m2[p * 3 + 2] + o_m2[(size_t)i * 3 + 2] + d.z * d.z * wab;
+    }
+    accum[p] = make_float4(m.x, m.y, m.z, 1.0f);
+    out_rgba8[p] = tonemap_rgba8(cam, m);
+}
+
+extern "C" __global__ void ptx_kat_math_kernel(int op, uint32_t n, const float* a, const float* b, float* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b[i], r = 0.0f;
+    switch (op) {
+        case 0: r = dm::sin_(x); break;
+        case 1: r = dm::cos_(x); break;
+        case 2: r = dm::asin_(x); break;
+        case 3: r = dm::acos_(x); break;
+        case 4: r = dm::log_(x); break;
+        case 5: r = dm::log2_(x); break;
+        case 6: r = dm::exp2_(x); break;
+        case 7: r = dm::atan2_(x, y); break;
+        case 8: r = dm::pow_(x, y); break;
+        case 9: r = dm::fmin_(x, y); break;
+        case 10: r = dm::fmax_(x, y); break;
+        case 11: r = dm::sqrt_(x); break;
+        case 12: r = x / y; break;
+        case 13: r = dm::fma_(x, y, x); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(const DScene sc, const ptx_camera cam, uint32_t n,
+                                                                            const float* rays, const float* max_t, uint32_t* hit_id,
+                                                                            float* hit_t, uint32_t* shadow) {
+    extern __shared__ StackEntry lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    StackEntry* st = lds_stack + (size_t)wave * sc.stack_entries * 64u + lane;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray ray;
+    ray.o = v3p(rays + 6 * (size_t)i);
+    ray.d = v3p(rays + 6 * (size_t)i + 3);
+    Ray r2 = ray;
+    float t;
+    uint32_t slot;
+    trace_closest(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot);
+    hit_id[i] = slot == PT_SLOT_NONE ? 0xFFFFFFFFu : slot_prim(sc, slot).fig;
+    hit_t[i] = slot == PT_SLOT_NONE ? PT_MAX_T : t;
+    if (shadow && max_t) shadow[i] = trace_shadow(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;
+}
+
+// ================================================================================================
+// Host side
+// ================================================================================================
+struct ptx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    bool have_scene = false;
+    DScene sc{};
+    std::vector<void*> scene_allocs;
+    // frame
+    uint32_t w = 0, h = 0;
+    uint32_t tx0 = 0, ty0 = 0, tw = 0, th = 0;
+    float4* accum = nullptr;
+    uint32_t* out = nullptr;
+    uint32_t* ids = nullptr;
+    float* m2 = nullptr;
+    bool moments = false;
+    float* dbg = nullptr;
+    uint32_t dbg_cap = 0;
+    unsigned long long* stats = nullptr;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> free_events;
+    double acc_ms = 0.0;
+    uint32_t acc_launches = 0;
+};
+
+namespace {
+
+int fail(ptx_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP,                          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                  \
+    } while (0)
+
+void free_scene(ptx_ctx* c) {
+    for (void* p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->have_scene = false;
+    memset(&c->sc, 0, sizeof(c->sc));
+}
+void free_frame(ptx_ctx* c) {
+    if (c->accum) (void)hipFree(c->accum);
+    if (c->out) (void)hipFree(c->out);
+    if (c->ids) (void)hipFree(c->ids);
+    if (c->m2) (void)hipFree(c->m2);
+    if (c->dbg) (void)hipFree(c->dbg);
+    c->accum = nullptr; c->out = nullptr; c->ids = nullptr; c->m2 = nullptr; c->dbg = nullptr;
+    c->dbg_cap = 0;
+}
+
+template <class T>
+int upload_vec(ptx_ctx* c, const std::vector<T>& v, const T** dst) {
+    *dst = nullptr;
+    size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    c->scene_allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T*)p;
+    return PTX_OK;
+}
+
+// Re-layout of one reference figure (src/scene/shape.rs:223-248) into the 64-byte intersector record.
+DPrim make_prim(const ptx_shape& f, uint32_t fig) {
+    DPrim g;
+    memset(&g, 0, sizeof(g));
+    g.type = f.csg_op == 1u ? (uint32_t)FIG_SKIP : f.shape_type;
+    g.fig = fig;
+    float* p = g.p;
+    p[0] = f.position[0]; p[1] = f.position[1]; p[2] = f.position[2];
+    auto put3 = [&](int at, const float* v) { p[at] = v[0]; p[at + 1] = v[1]; p[at + 2] = v[2]; };
+    switch (f.shape_type) {
+        case FIG_SPHERE: case FIG_CUBE: case FIG_TETRAHEDRON: case FIG_SKYBOX: case FIG_MEBIUS: p[3] = f.radius; break;
+        case FIG_PLANE: put3(3, f.normal); break;
+        case FIG_DISC: put3(3, f.normal); p[6] = f.radius; break;
+        case FIG_CYLINDER: put3(3, f.normal); p[6] = f.radius; p[7] = f.height; break;
+        case FIG_CONE: put3(3, f.normal); p[6] = f.radius; p[7] = f.height; p[8] = f.radius2; break;
+        case FIG_TORUS: p[3] = f.radius; p[4] = f.radius2; break;
+        case FIG_TRIANGLE: {
+            // e1 = v1 - v0, e2 = v2 - v0: the same single f32 subtractions triangle.wgsl:9-10 performs per ray.
+            volatile float e[6];
+            for (int i = 0; i < 3; i++) { e[i] = f.v1[i] - f.v0[i]; e[3 + i] = f.v2[i] - f.v0[i]; }
+            put3(0, f.v0);
+            for (int i = 0; i < 6; i++) p[3 + i] = e[i];
+            break;
+        }
+        case FIG_MANDELBULB: p[3] = f.radius; p[4] = f.v0[0]; p[5] = f.v0[1]; break;
+        case FIG_JULIA: p[3] = f.radius; p[4] = f.v0[1]; put3(5, f.rotation); p[8] = f.radius2; break;
+        case FIG_ELLIPSOID: p[3] = f.radius; p[4] = f.height; p[5] = f.radius2; break;
+        case FIG_PARABOLOID: case FIG_HYPERBOLOID: case FIG_PYRAMID: p[3] = f.radius; p[4] = f.height; break;
+        default: g.type = FIG_SKIP; break;  // unknown type: dispatch.wgsl:78-81 reports no hit
+    }
+    return g;
+}
+
+int collect_timing(ptx_ctx* c) {
+    for (auto& pr : c->pending) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventSynchronize(pr.second));
+        HIP_TRY(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->acc_ms += ms;
+        c->acc_launches += 1;
+        c->free_events.push_back(pr.first);
+        c->free_events.push_back(pr.second);
+    }
+    c->pending.clear();
+    return PTX_OK;
+}
+int get_event(ptx_ctx* c, hipEvent_t* e) {
+    if (!c->free_events.empty()) { *e = c->free_events.back(); c->free_events.pop_back(); return PTX_OK; }
+    HIP_TRY(c, hipEventCreate(e));
+    return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptx_create(int device, ptx_ctx** out) {
+    if (!out) return PTX_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PTX_ERR_HIP;
+    ptx_ctx* c = new ptx_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&c->stats, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return PTX_ERR_HIP;
+    }
+    *out = c;
+    return PTX_OK;
+}
+
+void ptx_destroy(ptx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& pr : c->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    free_scene(c);
+    free_frame(c);
+    if (c->stats) (void)hipFree(c->stats);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* ptx_last_error(const ptx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx_material* mats, uint32_t nmat,
+                     const ptx_bvh_node* nodes, uint32_t nnode, const uint32_t* prims, uint32_t nprim,
+                     const uint32_t* lights, uint32_t nlight, const uint32_t* infinite, uint32_t ninf,
+                     const uint32_t* tex_pixels, uint32_t npix, const ptx_texture_info* tex_infos, uint32_t ntex) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    if ((nfig && !figs) || (nmat && !mats) || (nnode && !nodes) || (nprim && !prims) || (nlight && !lights) ||
+        (ninf && !infinite) || (npix && !tex_pixels) || (ntex && !tex_infos))
+        return fail(c, PTX_ERR_BAD_ARG, "null array with non-zero count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    if (nprim > PT_REF_MASK || nnode > PT_REF_MASK) return fail(c, PTX_ERR_UNSUPPORTED, "more than 2^29 nodes or primitives");
+    for (uint32_t i = 0; i < nfig; i++)
+        if (figs[i].material_idx >= nmat) return fail(c, PTX_ERR_BAD_ARG, "figure material_idx out of range");
+
+    std::vector<DShade> shade(nfig);
+    std::vector<DNeg> negs;
+    int32_t sky_tex = -1;
+    float sky_color[3] = {0, 0, 0};
+    for (uint32_t i = 0; i < nfig; i++) {
+        const ptx_shape& f = figs[i];
+        const ptx_material& m = mats[f.material_idx];
+        shade[i].mat = m;
+        shade[i].texture_scale = f.texture_scale;
+        shade[i].uv0 = f._pad2; shade[i].uv1 = f._pad3; shade[i].uv2 = f._pad4;
+        if (f.csg_op == 1u) {
+            DNeg n;
+            memset(&n, 0, sizeof(n));
+            n.type = f.shape_type; n.radius = f.radius; n.radius2 = f.radius2; n.height = f.height;
+            memcpy(n.pos, f.position, 12);
+            memcpy(n.normal, f.normal, 12);
+            negs.push_back(n);
+        }
+        if (sky_tex < 0 && f.shape_type == FIG_SKYBOX && m.texture_id >= 0) {
+            sky_tex = m.texture_id;
+            memcpy(sky_color, m.base_color, 12);
+        }
+    }
+    std::vector<DPrim> dprims(nprim);
+    for (uint32_t s = 0; s < nprim; s++) {
+        if (prims[s] >= nfig) return fail(c, PTX_ERR_BAD_ARG, "bvh_prims entry out of range");
+        dprims[s] = make_prim(figs[prims[s]], prims[s]);
+    }
+    std::vector<DPrim> dinf;
+    for (uint32_t i = 0; i < ninf; i++) {
+        uint32_t fi = infinite[i];
+        if (fi == 0xFFFFFFFFu) continue;  // the reference's empty-list placeholder (bvh.wgsl:196-199)
+        if (fi >= nfig) return fail(c, PTX_ERR_BAD_ARG, "infinite_indices entry out of range");
+        if (figs[fi].csg_op == 1u) continue;  // bvh.wgsl:200-203
+        dinf.push_back(make_prim(figs[fi], fi));
+    }
+    std::vector<DLight> dl;
+    for (uint32_t i = 0; i < nlight; i++) {
+        uint32_t fi = lights[i];
+        if (fi == 0xFFFFFFFFu && nlight == 1u) break;  // placeholder list
+        if (fi >= nfig) return fail(c, PTX_ERR_BAD_ARG, "light_indices entry out of range");
+        const ptx_shape& f = figs[fi];
+        const ptx_material& m = mats[f.material_idx];
+        DLight L;
+        memcpy(L.pos, f.position, 12);
+        L.radius = f.radius;
+        volatile float le0 = m.emission[0] * m.emission_strength, le1 = m.emission[1] * m.emission_strength,
+                       le2 = m.emission[2] * m.emission_strength;
+        L.le[0] = le0; L.le[1] = le1; L.le[2] = le2;
+        volatile float a = 4.0f * PT_PI;  // lighting.wgsl:24: 4.0 * PI * r * r, left to right
+        a = a * f.radius;
+        a = a * f.radius;
+        volatile float pdf = 1.0f / a;
+        L.area_pdf = pdf;
+        dl.push_back(L);
+    }
+
+    // Node pairs.  Children must have larger indices than their parent (true of the reference's
+    // pre-order flatten, bvh.rs:188-213), which also rules out cycles.
+    std::vector<DNodePair> pairs;
+    uint32_t root_ref = 0, depth = 0, eff_nprim = 0;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    if (nnode > 0 && nprim > 0) {
+        std::vector<uint32_t> pair_of(nnode, 0xFFFFFFFFu);
+        uint32_t np = 0;
+        for (uint32_t i = 0; i < nnode; i++) {
+            const ptx_bvh_node& nd = nodes[i];
+            if (nd.prim_count == 0u) {
+                if (i + 1 >= nnode || nd.left_or_prim >= nnode || nd.left_or_prim <= i)
+                    return fail(c, PTX_ERR_BAD_ARG, "inner BVH node with child index out of order or range");
+                pair_of[i] = np++;
+            } else {
+                if (nd.prim_count > 7u) return fail(c, PTX_ERR_UNSUPPORTED, "BVH leaf with more than 7 primitives");
+                if ((uint64_t)nd.left_or_prim + nd.prim_count > nprim) return fail(c, PTX_ERR_BAD_ARG, "BVH leaf range outside bvh_prims");
+            }
+        }
+        pairs.resize(np);
+        auto child = [&](uint32_t ci, float* mn, float* mx, uint32_t* ref, uint32_t* cnt) {
+            const ptx_bvh_node& ch = nodes[ci];
+            memcpy(mn, ch.aabb_min, 12);
+            memcpy(mx, ch.aabb_max, 12);
+            if (ch.prim_count > 0u) { *ref = ch.left_or_prim; *cnt = ch.prim_count; }
+            else { *ref = pair_of[ci]; *cnt = 0u; }
+        };
+        for (uint32_t i = 0; i < nnode; i++) {
+            if (nodes[i].prim_count != 0u) continue;
+            DNodePair& pr = pairs[pair_of[i]];
+            child(i + 1, pr.lmin, pr.lmax, &pr.lref, &pr.lcnt);
+            child(nodes[i].left_or_prim, pr.rmin, pr.rmax, &pr.rref, &pr.rcnt);
+        }
+        const ptx_bvh_node& root = nodes[0];
+        memcpy(root_min, root.aabb_min, 12);
+        memcpy(root_max, root.aabb_max, 12);
+        root_ref = root.prim_count > 0u ? (root.left_or_prim | (root.prim_count << PT_REF_BITS)) : pair_of[0];
+        // Longest chain of inner nodes from the root: bounds the stack occupancy.
+        std::vector<std::pair<uint32_t, uint32_t>> todo;
+        todo.push_back({0u, 0u});
+        while (!todo.empty()) {
+            auto [ni, d] = todo.back();
+            todo.pop_back();
+            if (nodes[ni].prim_count != 0u) continue;
+            depth = d + 1 > depth ? d + 1 : depth;
+            todo.push_back({ni + 1, d + 1});
+            todo.push_back({nodes[ni].left_or_prim, d + 1});
+        }
+        eff_nprim = nprim;
+    }
+
+    DScene sc;
+    memset(&sc, 0, sizeof(sc));
+    int rc;
+    if ((rc = upload_vec(c, dprims, &sc.prims)) || (rc = upload_vec(c, dinf, &sc.inf)) || (rc = upload_vec(c, shade, &sc.shade)) ||
+        (rc = upload_vec(c, pairs, &sc.pairs)) || (rc = upload_vec(c, dl, &sc.lights)) || (rc = upload_vec(c, negs, &sc.negs))) {
+        free_scene(c);
+        return rc;
+    }
+    std::vector<uint32_t> px(tex_pixels, tex_pixels + npix);
+    std::vector<ptx_texture_info> ti(tex_infos, tex_infos + ntex);
+    for (auto& t : ti)
+        if (t.width == 0 || t.height == 0 || (uint64_t)t.offset + (uint64_t)t.width * t.height > npix) {
+            free_scene(c);
+            return fail(c, PTX_ERR_BAD_ARG, "texture info outside the pixel array");
+        }
+    if ((rc = upload_vec(c, px, &sc.tex_pixels)) || (rc = upload_vec(c, ti, &sc.tex_infos))) {
+        free_scene(c);
+        return rc;
+    }
+    sc.nprim = eff_nprim;
+    sc.ninf = (uint32_t)dinf.size();
+    sc.nlight = (uint32_t)dl.size();
+    sc.nneg = (uint32_t)negs.size();
+    sc.ntex = ntex;
+    sc.npix = npix;
+    sc.nfig = nfig;
+    sc.root_ref = root_ref;
+    memcpy(sc.root_min, root_min, 12);
+    memcpy(sc.root_max, root_max, 12);
+    sc.sky_tex = sky_tex;
+    memcpy(sc.sky_color, sky_color, 12);
+    uint32_t entries = depth + 1;
+    sc.stack_entries = entries > 31u ? 31u : entries;
+    c->sc = sc;
+    c->have_scene = true;
+    return PTX_OK;
+}
+
+int ptx_resize(ptx_ctx* c, uint32_t w, uint32_t h) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    if (w == 0 || h == 0 || (uint64_t)w * h > 0x7FFFFFFFull) return fail(c, PTX_ERR_BAD_ARG, "bad frame size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_frame(c);
+    size_t n = (size_t)w * h;
+    HIP_TRY(c, hipMalloc((void**)&c->accum, n * 16));
+    HIP_TRY(c, hipMalloc((void**)&c->out, n * 4));
+    HIP_TRY(c, hipMalloc((void**)&c->ids, n * 4));
+    if (c->moments) HIP_TRY(c, hipMalloc((void**)&c->m2, n * 12));
+    c->w = w; c->h = h;
+    c->tx0 = 0; c->ty0 = 0; c->tw = w; c->th = h;
+    return ptx_clear(c);
+}
+
+int ptx_set_tile(ptx_ctx* c, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_set_tile before ptx_resize");
+    if (w == 0 || h == 0 || (uint64_t)x0 + w > c->w || (uint64_t)y0 + h > c->h) return fail(c, PTX_ERR_BAD_ARG, "tile outside the frame");
+    if (c->dbg && (w != c->tw || h != c->th)) return fail(c, PTX_ERR_STATE, "tile size change while radiance capture is enabled");
+    c->tx0 = x0; c->ty0 = y0; c->tw = w; c->th = h;
+    return PTX_OK;
+}
+
+int ptx_clear(ptx_ctx* c) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_clear before ptx_resize");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->w * c->h;
+    HIP_TRY(c, hipMemsetAsync(c->accum, 0, n * 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->out, 0, n * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ids, 0xFF, n * 4, c->stream));
+    if (c->m2) HIP_TRY(c, hipMemsetAsync(c->m2, 0, n * 12, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    return PTX_OK;
+}
+
+int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n) {
+    if (!c || !cam) return PTX_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_upload_scene");
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_resize");
+    if (cam->width != c->w || cam->height != c->h) return fail(c, PTX_ERR_BAD_ARG, "camera width/height differ from the frame size");
+    if (n == 0) return PTX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TraceParams P;
+    memset(&P, 0, sizeof(P));
+    P.sc = c->sc;
+    P.cam = *cam;
+    P.first_frame = first_frame; P.first_sample = first_sample; P.n = n;
+    P.tile_x0 = c->tx0; P.tile_y0 = c->ty0; P.tile_w = c->tw; P.tile_h = c->th;
+    P.blocks_x = (c->tw + 15u) / 16u;
+    uint32_t blocks_y = (c->th + 15u) / 16u;
+    P.n_blocks = P.blocks_x * blocks_y;
+    P.accum = c->accum; P.out_rgba8 = c->out; P.primary_ids = c->ids;
+    P.m2 = c->moments ? c->m2 : nullptr;
+    P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;
+    P.stats = c->stats;
+    size_t lds = (size_t)PTX_WAVES_PER_BLOCK * c->sc.stack_entries * 64u * sizeof(StackEntry);
+    if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
+    hipEvent_t e0, e1;
+    int rc;
+    if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(ptx_trace_kernel, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    c->pending.push_back({e0, e1});
+    return PTX_OK;
+}
+
+int ptx_trace(ptx_ctx* c, const ptx_camera* cam) {
+    if (!c || !cam) return PTX_ERR_BAD_ARG;
+    return ptx_trace_n(c, cam, cam->frame_index, cam->sample_count, 1);
+}
+
+int ptx_sync(ptx_ctx* c) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+static int read_back(ptx_ctx* c, void* dst, const void* src, size_t bytes, const char* what) {
+    if (!c || !dst) return PTX_ERR_BAD_ARG;
+    if (!src) return fail(c, PTX_ERR_STATE, std::string(what) + ": buffer not allocated");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+int ptx_read_accum(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->accum : nullptr, c ? (size_t)c->w * c->h * 16 : 0, "ptx_read_accum"); }
+int ptx_read_output(ptx_ctx* c, uint8_t* o) { return read_back(c, o, c ? c->out : nullptr, c ? (size_t)c->w * c->h * 4 : 0, "ptx_read_output"); }
+int ptx_read_primary_ids(ptx_ctx* c, uint32_t* o) { return read_back(c, o, c ? c->ids : nullptr, c ? (size_t)c->w * c->h * 4 : 0, "ptx_read_primary_ids"); }
+int ptx_read_moments(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->m2 : nullptr, c ? (size_t)c->w * c->h * 12 : 0, "ptx_read_moments"); }
+
+int ptx_debug_capture(ptx_ctx* c, uint32_t max_samples) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_debug_capture before ptx_resize");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dbg) { (void)hipFree(c->dbg); c->dbg = nullptr; c->dbg_cap = 0; }
+    if (max_samples == 0) return PTX_OK;
+    size_t bytes = (size_t)max_samples * c->tw * c->th * 12;
+    HIP_TRY(c, hipMalloc((void**)&c->dbg, bytes));
+    HIP_TRY(c, hipMemset(c->dbg, 0, bytes));
+    c->dbg_cap = max_samples;
+    return PTX_OK;
+}
+int ptx_read_debug_radiance(ptx_ctx* c, float* out, uint32_t n) {
+    if (!c || !out) return PTX_ERR_BAD_ARG;
+    if (!c->dbg || n > c->dbg_cap) return fail(c, PTX_ERR_STATE, "radiance capture not enabled for that many samples");
+    return read_back(c, out, c->dbg, (size_t)n * c->tw * c->th * 12, "ptx_read_debug_radiance");
+}
+
+int ptx_enable_moments(ptx_ctx* c, int enable) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    c->moments = enable != 0;
+    if (c->moments && c->accum && !c->m2) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        size_t n = (size_t)c->w * c->h;
+        HIP_TRY(c, hipMalloc((void**)&c->m2, n * 12));
+        HIP_TRY(c, hipMemsetAsync(c->m2, 0, n * 12, c->stream));
+    }
+    return PTX_OK;
+}
+
+void* ptx_device_accum(ptx_ctx* c) { return c ? (void*)c->accum : nullptr; }
+void* ptx_device_moments(ptx_ctx* c) { return c ? (void*)c->m2 : nullptr; }
+
+int ptx_merge_moments(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, uint32_t n_a, const void* other_mean4,
+                      const void* other_m2, uint32_t n_b, const ptx_camera* cam) {
+    if (!c || !other_mean4 || !cam) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_merge_moments before ptx_resize");
+    if ((uint64_t)first_pixel + n_pixels > (uint64_t)c->w * c->h) return fail(c, PTX_ERR_BAD_ARG, "pixel range outside the frame");
+    if (n_pixels == 0 || n_b == 0) return PTX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(ptx_merge_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, c->stream, c->accum,
+                       (c->moments && other_m2) ? c->m2 : nullptr, c->out, first_pixel, n_pixels, (float)n_a,
+                       (const float4*)other_mean4, (const float*)other_m2, (float)n_b, *cam);
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
+    if (!c || !out) return PTX_ERR_BAD_ARG;
+    unsigned long long v[4];
+    int rc = read_back(c, v, c->stats, sizeof(v), "ptx_read_stats");
+    if (rc) return rc;
+    out->paths = v[0]; out->bounces = v[1]; out->shadow_rays = v[2];
+    return PTX_OK;
+}
+
+int ptx_kernel_time(ptx_ctx* c, float* total_ms, uint32_t* launches) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = collect_timing(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = (float)c->acc_ms;
+    if (launches) *launches = c->acc_launches;
+    c->acc_ms = 0.0;
+    c->acc_launches = 0;
+    return PTX_OK;
+}
+
+int ptx_kat_math(ptx_ctx* c, int op, uint32_t n, const float* a, const float* b, float* out) {
+    if (!c || !a || !b || !out) return PTX_ERR_BAD_ARG;
+    if (n == 0) return PTX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    size_t bytes = (size_t)n * 4;
+    int rc = PTX_OK;
+    if (hipMalloc((void**)&da, bytes) != hipSuccess || hipMalloc((void**)&db, bytes) != hipSuccess ||
+        hipMalloc((void**)&dout, bytes) != hipSuccess) {
+        rc = fail(c, PTX_ERR_OOM, "ptx_kat_math: hipMalloc");
+    } else if (hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(c, PTX_ERR_HIP, "ptx_kat_math: copy in");
+    } else {
+        hipLaunchKernelGGL(ptx_kat_math_kernel, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, op, n, da, db, dout);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(c, PTX_ERR_HIP, "ptx_kat_math: kernel or copy out");
+    }
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+int ptx_kat_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t n, const float* rays, const float* max_t, uint32_t* hit_id,
+                  float* hit_t, uint32_t* shadow) {
+    if (!c || !cam || !rays || !hit_id || !hit_t) return PTX_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTX_ERR_STATE, "ptx_kat_trace before ptx_upload_scene");
+    if (n == 0) return PTX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *dr = nullptr, *dm_ = nullptr, *dt = nullptr;
+    uint32_t *did = nullptr, *dsh = nullptr;
+    int rc = PTX_OK;
+    bool want_shadow = shadow && max_t;
+    if (hipMalloc((void**)&dr, (size_t)n * 24) != hipSuccess || hipMalloc((void**)&dm_, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void**)&dt, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&did, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void**)&dsh, (size_t)n * 4) != hipSuccess) {
+        rc = fail(c, PTX_ERR_OOM, "ptx_kat_trace: hipMalloc");
+    } else if (hipMemcpy(dr, rays, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess ||
+               (want_shadow && hipMemcpy(dm_, max_t, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+        rc = fail(c, PTX_ERR_HIP, "ptx_kat_trace: copy in");
+    } else {
+        size_t lds = (size_t)PTX_WAVES_PER_BLOCK * c->sc.stack_entries * 64u * sizeof(StackEntry);
+        hipLaunchKernelGGL(ptx_kat_trace_kernel, dim3((n + PTX_BLOCK - 1u) / PTX_BLOCK), dim3(PTX_BLOCK), lds, c->stream, c->sc, *cam, n,
+                           dr, want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(hit_id, did, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hit_t, dt, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            (want_shadow && hipMemcpy(shadow, dsh, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = fail(c, PTX_ERR_HIP, "ptx_kat_trace: kernel or copy out");
+    }
+    if (dr) (void)hipFree(dr);
+    if (dm_) (void)hipFree(dm_);
+    if (dt) (void)hipFree(dt);
+    if (did) (void)hipFree(did);
+    if (dsh) (void)hipFree(dsh);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+"""ctypes view of the ptx355 C ABI (include/ptx355.h): one PathTracer = one ptx_ctx = one GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .records import CAMERA_DT, MATERIAL_DT, NODE_DT, SHAPE_DT, TEXINFO_DT
+
+
+class PtxError(RuntimeError):
+    pass
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dt) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a
+
+
+class PathTracer:
+    """Mirrors the reference's render seam: upload scene buffers, size the frame, then one `trace` per
+    frame (or `trace_n` for a batch) and read the accumulation / output images back."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.ptx_create(device, C.byref(h))
+        if rc != 0 or not h:
+            raise PtxError(f"ptx_create(device={device}) failed with {rc}: no usable HIP device")
+        self.h = h
+        self.device = device
+        self.width = self.height = 0
+        self.tile = (0, 0, 0, 0)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ptx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int, what: str):
+        if rc != 0:
+            raise PtxError(f"{what} failed ({rc}): {self.lib.ptx_last_error(self.h).decode()}")
+
+    def upload_scene(self, figs, mats, nodes, prims, lights, infinite, tex_pixels, tex_infos):
+        figs, mats, nodes = _arr(figs, SHAPE_DT), _arr(mats, MATERIAL_DT), _arr(nodes, NODE_DT)
+        prims, lights, infinite = _arr(prims, np.uint32), _arr(lights, np.uint32), _arr(infinite, np.uint32)
+        tex_pixels, tex_infos = _arr(tex_pixels, np.uint32), _arr(tex_infos, TEXINFO_DT)
+        self._ck(self.lib.ptx_upload_scene(self.h, _p(figs), len(figs), _p(mats), len(mats), _p(nodes), len(nodes),
+                                           _p(prims), len(prims), _p(lights), len(lights), _p(infinite), len(infinite),
+                                           _p(tex_pixels), len(tex_pixels), _p(tex_infos), len(tex_infos)), "ptx_upload_scene")
+
+    def resize(self, width: int, height: int):
+        self._ck(self.lib.ptx_resize(self.h, width, height), "ptx_resize")
+        self.width, self.height = width, height
+        self.tile = (0, 0, width, height)
+
+    def set_tile(self, x0: int, y0: int, w: int, h: int):
+        self._ck(self.lib.ptx_set_tile(self.h, x0, y0, w, h), "ptx_set_tile")
+        self.tile = (x0, y0, w, h)
+
+    def clear(self):
+        self._ck(self.lib.ptx_clear(self.h), "ptx_clear")
+
+    def trace(self, cam: np.ndarray):
+        cam = _arr(cam, CAMERA_DT)
+        self._ck(self.lib.ptx_trace(self.h, _p(cam)), "ptx_trace")
+
+    def trace_n(self, cam: np.ndarray, first_frame: int, first_sample: int, n: int):
+        cam = _arr(cam, CAMERA_DT)
+        self._ck(self.lib.ptx_trace_n(self.h, _p(cam), first_frame, first_sample, n), "ptx_trace_n")
+
+    def sync(self):
+        self._ck(self.lib.ptx_sync(self.h), "ptx_sync")
+
+    def read_accum(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._ck(self.lib.ptx_read_accum(self.h, _p(out)), "ptx_read_accum")
+        return out
+
+    def read_output(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._ck(self.lib.ptx_read_output(self.h, _p(out)), "ptx_read_output")
+        return out
+
+    def read_primary_ids(self) -> np.ndarray:
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        self._ck(self.lib.ptx_read_primary_ids(self.h, _p(out)), "ptx_read_primary_ids")
+        return out
+
+    def debug_capture(self, max_samples: int):
+        self._ck(self.lib.ptx_debug_capture(self.h, max_samples), "ptx_debug_capture")
+
+    def read_debug_radiance(self, n: int) -> np.ndarray:
+        out = np.empty((n, self.tile[3], self.tile[2], 3), dtype=np.float32)
+        self._ck(self.lib.ptx_read_debug_radiance(self.h, _p(out), n), "ptx_read_debug_radiance")
+        return out
+
+    def enable_moments(self, on: bool = True):
+        self._ck(self.lib.ptx_enable_moments(self.h, 1 if on else 0), "ptx_enable_moments")
+
+    def read_moments(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._ck(self.lib.ptx_read_moments(self.h, _p(out)), "ptx_read_moments")
+        return out
+
+    def device_accum_ptr(self) -> int:
+        return int(self.lib.ptx_device_accum(self.h) or 0)
+
+    def device_moments_ptr(self) -> int:
+        return int(self.lib.ptx_device_moments(self.h) or 0)
+
+    def merge_moments(self, first_pixel: int, n_pixels: int, n_a: int, other_mean4_ptr: int, other_m2_ptr: int, n_b: int, cam):
+        cam = _arr(cam, CAMERA_DT)
+        self._ck(self.lib.ptx_merge_moments(self.h, first_pixel, n_pixels, n_a, C.c_void_p(other_mean4_ptr),
+                                            C.c_void_p(other_m2_ptr) if other_m2_ptr else None, n_b, _p(cam)), "ptx_merge_moments")
+
+    def stats(self) -> dict:
+        s = _lib.PtxStats()
+        self._ck(self.lib.ptx_read_stats(self.h, C.byref(s)), "ptx_read_stats")
+        return {"paths": s.paths, "bounces": s.bounces, "shadow_rays": s.shadow_rays}
+
+    def kernel_time(self) -> Tuple[float, int]:
+        ms, n = C.c_float(), C.c_uint32()
+        self._ck(self.lib.ptx_kernel_time(self.h, C.byref(ms), C.byref(n)), "ptx_kernel_time")
+        return float(ms.value), int(n.value)
+
+    KAT_OPS = {"sin": 0, "cos": 1, "asin": 2, "acos": 3, "log": 4, "log2": 5, "exp2": 6, "atan2": 7, "pow": 8,
+               "min": 9, "max": 10, "sqrt": 11, "div": 12, "fma_aba": 13}
+
+    def kat_math(self, op: str, a, b=None) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)
+        out = np.empty_like(a)
+        self._ck(self.lib.ptx_kat_math(self.h, self.KAT_OPS[op], a.size, _p(a), _p(b), _p(out)), "ptx_kat_math")
+        return out
+
+    def kat_trace(self, cam, rays, max_t=None):
+        cam = _arr(cam, CAMERA_DT)
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = len(rays)
+        hid, ht = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.float32)
+        sh = np.empty(n, dtype=np.uint32) if max_t is not None else None
+        mt = np.ascontiguousarray(max_t, dtype=np.float32) if max_t is not None else None
+        self._ck(self.lib.ptx_kat_trace(self.h, _p(cam), n, _p(rays), _p(mt), _p(hid), _p(ht), _p(sh)), "ptx_kat_trace")
+        return hid, ht, sh
