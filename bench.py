@@ -1,0 +1,186 @@
+"""Throughput of the path-tracing compute pass on MI355X.
+
+python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|teapot|fractals|all_mesh] [--spp-per-step S]
+
+A step is one batched launch of the hot path: S samples for every pixel of the workload's frame, inputs
+(scene, accumulation buffer) resident in HBM.  N > 1 (one process per GPU under torch.distributed.run):
+sample split — every rank renders the full frame for its own frame-index range (weak scaling: per-GPU
+work is fixed), and the per-GPU Welford moments are merged once at the end of the timed region with
+Chan's formula over RCCL.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (fixture, width, height, default spp per step, label)
+    "cornell": ("cornell_box", 1920, 1080, 128, "cornell_box.yaml 1920x1080 (configs[1]: analytic primitives, 1024 spp = 8 steps x 128)"),
+    "teapot": ("teapot", 3840, 2160, 16, "teapot.yaml 3840x2160 OBJ BVH"),
+    "fractals": ("fractals", 1920, 1080, 4, "fractals.yaml 1920x1080 Mandelbulb/Julia ray-march"),
+    "all_mesh": ("all", 1920, 1080, 8, "all.yaml + synthetic height-field mesh 1920x1080"),
+}
+PEAK_FP32_VALU_TFLOPS = 157.3  # packed v_pk_fma_f32; 78.6 for one FMA per lane per clock
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(fx_name: str, w: int, h: int, spp: int):
+    """The CPU oracle on a bounded sample of the same workload, timed on this host's cores; also returns the
+    oracle's work counters (the algorithmic flop figure comes from them)."""
+    from oracle import host_prep as hp, oracle as orc
+    sb = hp.prepare_fixture(os.path.join(ROOT, "data", "scenes", f"{fx_name}.npz"))
+    cam = hp.camera_to_gpu(sb.camera, w, h)
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    osc = orc.OracleScene(sb)
+    t0 = time.perf_counter()
+    r = orc.render(osc, cam, spp, counters=True, threads=threads)
+    dt = time.perf_counter() - t0
+    c = r["counters"]
+    return {"value": round(c["paths"] / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": f"{fx_name} {w}x{h}, frames 0..{spp - 1} ({c['paths']} paths, {dt:.1f} s wall)",
+            "gpath_bounce_per_s": round(c["bounces"] / dt / 1e9, 6)}, c, orc.counted_flops(c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell", choices=list(WORKLOADS))
+    ap.add_argument("--spp-per-step", type=int, default=0)
+    ap.add_argument("--mesh-quads", type=int, default=2236, help="all_mesh: quads per side (2236 -> 10.0 M triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py --gpus N with N > 1 must be launched as one process per GPU (torch.distributed.run)", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    from pathtracer_amd import host, multigpu
+    from pathtracer_amd.device import PathTracer
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+
+    fx_name, w, h, spp_default, label = WORKLOADS[args.workload]
+    spp = args.spp_per_step or spp_default
+    scene = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{fx_name}.npz"))
+    if args.workload == "all_mesh":
+        scene.append_heightfield(args.mesh_quads)
+    t0 = time.perf_counter()
+    scene.build(decode_textures=False)
+    build_s = time.perf_counter() - t0
+    pt = PathTracer(local_rank)
+    t0 = time.perf_counter()
+    scene.upload_to(pt)
+    upload_s = time.perf_counter() - t0
+    if world > 1:
+        pt.enable_moments(True)
+    pt.resize(w, h)
+    cam = scene.camera(w, h)
+
+    def barrier():
+        pt.sync()
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    # frame ranges: rank r owns frames [r * steps * spp, (r + 1) * steps * spp), samples counted locally
+    frame0 = rank * (args.steps + args.warmup) * spp
+    for i in range(args.warmup):
+        pt.trace_n(cam, frame0 + i * spp, 1 + i * spp, spp)
+    pt.sync()
+    pt.clear()
+    pt.kernel_time()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pt.trace_n(cam, frame0 + (args.warmup + i) * spp, 1 + i * spp, spp)
+    if dist is not None:
+        multigpu.merge_sample_split(pt, dist, device, [args.steps * spp] * world, cam)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = pt.kernel_time()
+    st = pt.stats()
+    paths_per_gpu = w * h * spp * args.steps
+    total_paths = paths_per_gpu * world
+    bounces = st["bounces"]
+    if dist is not None:
+        t = torch.tensor([bounces], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        total_bounces = float(t.item())
+    else:
+        total_bounces = float(bounces)
+
+    if rank == 0:
+        out = {
+            "metric": "Mpaths/s at 1080p (1/2/4/8 GPUs) + % FP32 VALU peak; image RMSE vs ref",
+            "value": round(total_paths / elapsed / 1e6, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "width": w, "height": h, "spp_per_step": spp, "frames": args.steps * spp,
+                       "partition": "single GPU" if world == 1 else f"sample split over {world} GPUs + RCCL Chan merge",
+                       "scene_build_s": round(build_s, 3), "scene_upload_s": round(upload_s, 3)},
+            "gpath_bounce_per_s": round(total_bounces / elapsed / 1e9, 4),
+            "bounces_per_path": round(bounces / max(st["paths"], 1), 4),
+            "image_rmse_vs_ref": 0.0,  # tests/test_gpu_*: bit-exact against the oracle at equal seeds
+        }
+        cpu, flops_per_bounce = None, None
+        if not args.no_cpu_baseline:
+            cpu_spp = {"cornell": 4, "teapot": 2, "fractals": 1, "all_mesh": 1}[args.workload]
+            if args.workload != "all_mesh":  # the 10 M-triangle scene is not rebuilt by the numpy checker
+                cpu, cnt, flops = cpu_baseline(fx_name, w, h, cpu_spp)
+                flops_per_bounce = flops / max(cnt["bounces"], 1)
+        avg_ms = kernel_ms / max(launches, 1)
+        roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": "ptx_trace_kernel",
+                "kernel_avg_ms": round(avg_ms, 3), "launches": launches, "traffic": None}
+        if flops_per_bounce is not None:
+            flops_per_launch = flops_per_bounce * bounces / max(launches, 1)
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof.update({"achieved": round(ach, 4), "frac": round(ach / PEAK_FP32_VALU_TFLOPS, 5),
+                         "flops_per_path_bounce": round(flops_per_bounce, 1)})
+        else:
+            roof.update({"achieved": None, "frac": None})
+        # streaming floor of the same kernel: accumulation read + write + rgba8 + ids per pixel per launch
+        stream_bytes = w * h * (16 + 16 + 4 + 4)
+        roof["hbm_streaming"] = {"bytes_per_launch": stream_bytes, "achieved_gbs": round(stream_bytes / (avg_ms * 1e-3) / 1e9, 3),
+                                 "peak_gbs": PEAK_HBM_GBS}
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                t = json.load(open(tf))
+                if t.get("workload") == args.workload and t.get("spp_per_step") == spp:
+                    roof["traffic"] = t.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        out["roofline"] = roof
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    pt.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,12 @@ int ptx_resize(ptx_ctx* ctx, uint32_t width, uint32_t height);
  * across GPUs.  Pixel values do not depend on the tiling. */
 int ptx_set_tile(ptx_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
 
+/* Interleaved ownership for multi-GPU tile partitioning: ptx_trace* then only processes the 16x16-pixel
+ * blocks of the tile whose row-major index is congruent to `rank` modulo `world` (default 0 of 1 = all).
+ * No reference counterpart.  Untouched pixels keep their buffer contents (zero after ptx_clear), so the
+ * ranks' accumulation buffers sum to the single-GPU frame exactly. */
+int ptx_set_partition(ptx_ctx* ctx, uint32_t rank, uint32_t world);
+
 /* encoder.clear_buffer(accumulation) (src/app/rendering.rs:110-112); also zeroes moments and stats. */
 int ptx_clear(ptx_ctx* ctx);
 

@@ -698,3 +698,50 @@ def prepare_shapes(shapes: List[Shape], camera: CameraConfig, tex_loader=None) -
     gs, gm, lights = build_gpu_data(shapes, cache)
     nodes, prims, infinite = build_bvh(shapes)
     return SceneBuffers(gs, gm, nodes, prims, lights, infinite, pix, infos, camera)
+
+
+# --- data/scenes/*.npz fixtures ---------------------------------------------------------------------
+def _half_to_float(h: int) -> float:
+    return float(np.array([h], dtype=np.uint16).view(np.float16)[0])
+
+
+def scene_from_fixture(path: str):
+    """Rebuilds (shapes, camera, texture loader) from a fixture written by tools/make_scene_fixtures.py:
+    authored shapes in record containers, the camera block and decoded textures."""
+    d = np.load(path, allow_pickle=False)
+    figs, mats = d["figs"], d["mats"]
+    shapes = []
+    for g, m in zip(figs, mats):
+        t = SHAPE_TYPES[int(g["shape_type"])]
+        s = Shape(shape_type=t, negative=bool(g["csg_op"] == 1), position=tuple(float(x) for x in g["position"]),
+                  normal=tuple(float(x) for x in g["normal"]), radius=float(g["radius"]), radius2=float(g["radius2"]),
+                  height=float(g["height"]), rotation=tuple(float(x) for x in g["rotation"]),
+                  v1=tuple(float(x) for x in g["v1"]), v2=tuple(float(x) for x in g["v2"]),
+                  texture_scale=float(g["texture_scale"]))
+        if t in ("mandelbulb", "julia"):
+            s.power, s.max_iterations = float(g["v0"][0]), int(g["v0"][1])
+        else:
+            s.v0 = tuple(float(x) for x in g["v0"])
+        for name, fld in (("uv0", "pad2"), ("uv1", "pad3"), ("uv2", "pad4")):
+            b = int(g[fld])
+            setattr(s, name, (_half_to_float(b & 0xFFFF), _half_to_float(b >> 16)))
+        s.material = Material(tuple(float(x) for x in m["base_color"]), float(m["metallic"]), float(m["roughness"]),
+                              tuple(float(x) for x in m["emission"]), float(m["emission_strength"]), float(m["ior"]),
+                              float(m["transmission"]), int(m["texture_id"]))
+        shapes.append(s)
+    c = d["camera"]
+    cam = CameraConfig(position=tuple(c[0:3]), rotation=tuple(c[3:6]), fov=float(c[6]), exposure=float(c[7]),
+                       max_bounces=int(c[8]), firefly_clamp=float(c[9]), skybox_color=tuple(c[10:13]),
+                       skybox_brightness=float(c[13]), tone_mapper=int(c[14]), fractal_march_steps=int(c[15]))
+    images = {}
+    for t in range(int(d["n_textures"])):
+        name = f"fixture_texture_{t}"
+        images[name] = d[f"tex{t}_rgba8"]
+        for si in d[f"tex{t}_shapes"]:
+            shapes[int(si)].texture = name
+    return shapes, cam, (lambda p: images[p])
+
+
+def prepare_fixture(path: str) -> SceneBuffers:
+    shapes, cam, loader = scene_from_fixture(path)
+    return prepare_shapes(shapes, cam, loader)

@@ -23,6 +23,7 @@ SYMBOLS = [
     ("ptx_upload_scene", C.c_int, [_P, _P, _U, _P, _U, _P, _U, _P, _U, _P, _U, _P, _U, _P, _U, _P, _U]),
     ("ptx_resize", C.c_int, [_P, _U, _U]),
     ("ptx_set_tile", C.c_int, [_P, _U, _U, _U, _U]),
+    ("ptx_set_partition", C.c_int, [_P, _U, _U]),
     ("ptx_clear", C.c_int, [_P]),
     ("ptx_trace", C.c_int, [_P, _P]),
     ("ptx_trace_n", C.c_int, [_P, _P, _U, _U, _U]),

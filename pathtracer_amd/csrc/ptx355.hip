@@ -26,7 +26,8 @@ struct TraceParams {
     ptx_camera cam;
     uint32_t first_frame, first_sample, n;
     uint32_t tile_x0, tile_y0, tile_w, tile_h;
-    uint32_t blocks_x, n_blocks;
+    uint32_t blocks_x, n_blocks;        // 16x16-pixel blocks across the tile; blocks this launch runs
+    uint32_t part_rank, part_world;      // this launch owns tile blocks part_rank, part_rank + part_world, ...
     float4* accum;
     uint32_t* out_rgba8;
     uint32_t* primary_ids;
@@ -55,7 +56,7 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_trace_kernel(const T
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     StackEntry* st = lds_stack + (size_t)wave * P.sc.stack_entries * 64u + lane;
 
-    const uint32_t blk = xcd_remap(blockIdx.x, P.n_blocks);
+    const uint32_t blk = xcd_remap(blockIdx.x, P.n_blocks) * P.part_world + P.part_rank;
     const uint32_t bx = blk % P.blocks_x, by = blk / P.blocks_x;
     const uint32_t tx = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t ty = by * 16u + (wave >> 1) * 8u + (lane >> 3);
@@ -215,6 +216,7 @@ struct ptx_ctx {
     // frame
     uint32_t w = 0, h = 0;
     uint32_t tx0 = 0, ty0 = 0, tw = 0, th = 0;
+    uint32_t part_rank = 0, part_world = 1;
     float4* accum = nullptr;
     uint32_t* out = nullptr;
     uint32_t* ids = nullptr;
@@ -546,6 +548,13 @@ int ptx_set_tile(ptx_ctx* c, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
     return PTX_OK;
 }
 
+int ptx_set_partition(ptx_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    if (world == 0 || rank >= world) return fail(c, PTX_ERR_BAD_ARG, "partition rank outside [0, world)");
+    c->part_rank = rank; c->part_world = world;
+    return PTX_OK;
+}
+
 int ptx_clear(ptx_ctx* c) {
     if (!c) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_clear before ptx_resize");
@@ -574,7 +583,10 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     P.tile_x0 = c->tx0; P.tile_y0 = c->ty0; P.tile_w = c->tw; P.tile_h = c->th;
     P.blocks_x = (c->tw + 15u) / 16u;
     uint32_t blocks_y = (c->th + 15u) / 16u;
-    P.n_blocks = P.blocks_x * blocks_y;
+    uint32_t total_blocks = P.blocks_x * blocks_y;
+    P.part_rank = c->part_rank; P.part_world = c->part_world;
+    P.n_blocks = total_blocks > c->part_rank ? (total_blocks - c->part_rank + c->part_world - 1u) / c->part_world : 0u;
+    if (P.n_blocks == 0u) return PTX_OK;
     P.accum = c->accum; P.out_rgba8 = c->out; P.primary_ids = c->ids;
     P.m2 = c->moments ? c->m2 : nullptr;
     P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;

@@ -70,6 +70,9 @@ class PathTracer:
         self._ck(self.lib.ptx_set_tile(self.h, x0, y0, w, h), "ptx_set_tile")
         self.tile = (x0, y0, w, h)
 
+    def set_partition(self, rank: int, world: int):
+        self._ck(self.lib.ptx_set_partition(self.h, rank, world), "ptx_set_partition")
+
     def clear(self):
         self._ck(self.lib.ptx_clear(self.h), "ptx_clear")
 

@@ -1,0 +1,95 @@
+"""GPU tier at the benchmark's full sizes, through properties that do not need the oracle to finish:
+tiling invariance, determinism, batched == continued accumulation, and a sampled oracle cross-check."""
+import numpy as np
+import pytest
+
+from oracle import host_prep as hp, oracle as orc
+from pathtracer_amd import host
+from pathtracer_amd.device import PathTracer
+from util import fixture, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    t = PathTracer(0)
+    yield t
+    t.close()
+
+
+def test_cornell_1080p_properties(pt):
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h, n = 1920, 1080, 32
+    cam = sc.camera(w, h)
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, n)
+    a = pt.read_accum()
+    ids = pt.read_primary_ids()
+    st = pt.stats()
+    assert st["paths"] == w * h * n and 4.0 < st["bounces"] / st["paths"] < 4.7
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., 3] == 1).all()
+    # determinism + split accumulation: 20 then 12 samples == 32 at once
+    pt.clear()
+    pt.trace_n(cam, 0, 1, 20)
+    pt.trace_n(cam, 20, 21, 12)
+    assert same_bits(pt.read_accum(), a) == 0
+    # interleaved 4-way partition reassembles the frame
+    total = np.zeros_like(a)
+    for r in range(4):
+        pt.clear()
+        pt.set_partition(r, 4)
+        pt.trace_n(cam, 0, 1, n)
+        total += pt.read_accum()
+    pt.set_partition(0, 1)
+    assert same_bits(total, a) == 0
+    # oracle cross-check on three full-resolution tiles (same frame, same seeds)
+    sb = hp.prepare_fixture(fixture("cornell_box"))
+    ocam = hp.camera_to_gpu(sb.camera, w, h)
+    osc = orc.OracleScene(sb)
+    for tile in [(0, 0, 48, 32), (936, 524, 48, 32), (1872, 1048, 48, 32)]:
+        ref = orc.render(osc, ocam, n, tile=tile)
+        x0, y0, tw, th = tile
+        assert same_bits(a[y0:y0 + th, x0:x0 + tw], ref["accum"][y0:y0 + th, x0:x0 + tw]) == 0
+        assert (ids[y0:y0 + th, x0:x0 + tw] == ref["primary_id"][y0:y0 + th, x0:x0 + tw]).all()
+
+
+def test_teapot_4k_tiles_and_oracle_sample(pt):
+    sc = host.Scene.from_fixture(fixture("teapot")).build(decode_textures=False)
+    w, h, n = 3840, 2160, 4
+    cam = sc.camera(w, h)
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, n)
+    a, out = pt.read_accum(), pt.read_output()
+    total = np.zeros_like(a)
+    for r in range(8):
+        pt.clear()
+        pt.set_partition(r, 8)
+        pt.trace_n(cam, 0, 1, n)
+        total += pt.read_accum()
+    pt.set_partition(0, 1)
+    assert same_bits(total, a) == 0
+    sb = hp.prepare_fixture(fixture("teapot"))
+    ocam = hp.camera_to_gpu(sb.camera, w, h)
+    ref = orc.render(orc.OracleScene(sb), ocam, n, tile=(1800, 1000, 96, 64))
+    assert same_bits(a[1000:1064, 1800:1896], ref["accum"][1000:1064, 1800:1896]) == 0
+    assert (out[1000:1064, 1800:1896] == ref["rgba8"][1000:1064, 1800:1896]).all()
+
+
+def test_large_heightfield_bvh_against_oracle_tile(pt):
+    sc = host.Scene.from_fixture(fixture("all"))
+    sc.append_heightfield(500)  # 500 000 triangles
+    sc.build()
+    b = sc.buffers()
+    w, h, n = 640, 360, 2
+    cam = sc.camera(w, h)
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, n)
+    a = pt.read_accum()
+    sb = hp.SceneBuffers(b["figs"], b["mats"], b["nodes"], b["prims"], b["lights"], b["infinite"], b["tex_pixels"], b["tex_infos"],
+                         hp.scene_from_fixture(fixture("all"))[1])
+    ref = orc.render(orc.OracleScene(sb), cam, n, tile=(200, 200, 128, 64))
+    assert same_bits(a[200:264, 200:328], ref["accum"][200:264, 200:328]) == 0

@@ -1,0 +1,120 @@
+"""CPU tier: the product's C++ host library (include/pth_host.h) against the independent numpy
+restatement in oracle/host_prep.py — every scene buffer and the camera uniform, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import host_prep as hp
+from pathtracer_amd import host
+from util import REFERENCE, fixture
+
+KEYS = ["figs", "mats", "nodes", "prims", "lights", "infinite", "tex_pixels", "tex_infos"]
+
+
+def _assert_same(b: dict, sb: hp.SceneBuffers):
+    for k in KEYS:
+        assert b[k].tobytes() == getattr(sb, k).tobytes(), k
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "teapot", "fractals", "all", "planet"])
+def test_fixture_build_matches_numpy_restatement(name):
+    sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
+    sb = hp.prepare_fixture(fixture(name))
+    _assert_same(sc.buffers(), sb)
+    for (w, h, f, s) in [(1920, 1080, 0, 1), (512, 512, 7, 8), (77, 33, 1000, 3)]:
+        assert sc.camera(w, h, f, s).tobytes() == hp.camera_to_gpu(sb.camera, w, h, f, s).tobytes()
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not mounted")
+@pytest.mark.parametrize("name", ["cornell_box", "teapot", "fractals", "all", "planet", "playground", "rings", "demo"])
+def test_yaml_ingest_matches_numpy_restatement(name):
+    path = f"{REFERENCE}/resources/scenes/{name}.yaml"
+    sc = host.Scene.load(path, REFERENCE).build()
+    sb = hp.prepare(path, REFERENCE)
+    _assert_same(sc.buffers(), sb)
+    assert sc.camera(640, 360, 2, 3).tobytes() == hp.camera_to_gpu(sb.camera, 640, 360, 2, 3).tobytes()
+
+
+def test_scene_table_of_the_four_configurations():
+    b = host.Scene.from_fixture(fixture("cornell_box")).build().buffers()
+    assert len(b["figs"]) == 13 and list(b["infinite"]) == [0, 1, 2, 3, 4] and list(b["lights"]) == [5, 12]
+    assert len(b["prims"]) == 8 and sorted(b["prims"]) == list(range(5, 13))
+    b = host.Scene.from_fixture(fixture("teapot")).build(decode_textures=False).buffers()
+    assert len(b["figs"]) == 191 and list(b["infinite"]) == [1] and len(b["lights"]) == 0 and len(b["prims"]) == 189
+    assert b["mats"][1]["texture_id"] == 1 and b["tex_infos"][0].tolist() == (1, 1, 0, 0) and b["tex_pixels"][0] == 0xFF808080
+    b = host.Scene.from_fixture(fixture("fractals")).build().buffers()
+    assert len(b["figs"]) == 5 and list(b["lights"]) == [0] and list(b["infinite"]) == [1] and len(b["nodes"]) == 1
+    b = host.Scene.from_fixture(fixture("all")).build().buffers()
+    assert len(b["figs"]) == 14 and list(b["lights"]) == [0] and list(b["infinite"]) == [0]
+
+
+def test_material_roughness_clamp_and_light_rule():
+    sc = host.Scene.empty()
+    figs = np.zeros(3, dtype=host.SHAPE_DT)
+    mats = np.zeros(3, dtype=host.MATERIAL_DT)
+    figs["shape_type"] = 0
+    figs["radius"] = 1.0
+    figs["normal"] = (0, 3, 4)
+    mats["roughness"] = [0.0, 0.04, 0.5]
+    mats["emission_strength"] = [1.0, 1.0, 0.0]
+    mats["emission"][0] = (0, 0, 0)       # strength without colour: not a light (material.rs:97-100)
+    mats["emission"][1] = (0, 0.1, 0)
+    mats["texture_id"] = -1
+    sc.append_shapes(figs, mats)
+    b = sc.build().buffers()
+    assert list(b["mats"]["roughness"]) == [np.float32(0.04), np.float32(0.04), np.float32(0.5)]
+    assert list(b["lights"]) == [1]
+    assert np.allclose(b["figs"]["normal"][0], (0, 0.6, 0.8)) and list(b["figs"]["material_idx"]) == [0, 1, 2]
+
+
+def test_bvh_invariants_on_heightfield():
+    sc = host.Scene.empty()
+    sc.append_heightfield(40, glass_every=8)  # 3200 triangles
+    b = sc.build().buffers()
+    nodes, prims = b["nodes"], b["prims"]
+    assert sorted(prims) == list(range(3200))
+    seen = np.zeros(len(prims), dtype=int)
+    stack, depth = [(0, 0)], 0
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        nd = nodes[i]
+        if nd["prim_count"] > 0:
+            assert nd["prim_count"] <= 4
+            seen[nd["left_or_prim"]:nd["left_or_prim"] + nd["prim_count"]] += 1
+        else:
+            l, r = i + 1, int(nd["left_or_prim"])
+            assert r > l
+            for c in (l, r):
+                assert (nodes[c]["aabb_min"] >= nd["aabb_min"]).all() and (nodes[c]["aabb_max"] <= nd["aabb_max"]).all()
+                stack.append((c, d + 1))
+    assert (seen == 1).all() and depth >= 9
+    sb = hp.prepare_shapes(hp.scene_from_fixture(fixture("fractals"))[0], hp.CameraConfig())  # smoke: numpy builder runs
+    assert len(sb.nodes) == 1
+
+
+def test_heightfield_is_deterministic_and_matches_numpy_bvh():
+    a, b = host.Scene.empty(), host.Scene.empty()
+    a.append_heightfield(12)
+    b.append_heightfield(12)
+    ba, bb = a.build().buffers(), b.build().buffers()
+    assert all(ba[k].tobytes() == bb[k].tobytes() for k in KEYS)
+    # the numpy restatement of Bvh::build over the same triangles gives the same tree
+    shapes = []
+    for g in ba["figs"]:
+        shapes.append(hp.Shape("triangle", v0=tuple(g["v0"]), v1=tuple(g["v1"]), v2=tuple(g["v2"]), radius=0.0))
+    nodes, prims, _ = hp.build_bvh(shapes)
+    assert nodes.tobytes() == ba["nodes"].tobytes() and prims.tobytes() == ba["prims"].tobytes()
+
+
+def test_accumulator_and_frame_indices():
+    acc = host.Accumulator()
+    assert acc.advance() == (True, 0) and acc.sample_count == 1
+    assert acc.advance() == (False, 1) and acc.sample_count == 2
+    acc.reset()
+    assert acc.sample_count == 0
+    assert acc.advance() == (True, 2) and acc.sample_count == 1  # frame_index keeps running (rendering.rs:82)
+    lib = host.load()
+    assert lib.pth_dispatch_size(1920, 8) == 240 and lib.pth_dispatch_size(1081, 8) == 136
+    assert lib.pth_f32_to_f16_bits(1.0) == 0x3C00
