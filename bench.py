@@ -97,8 +97,8 @@ def main():
 
     def barrier():
         pt.sync()
-        torch.cuda.synchronize(device)
         if dist is not None:
+            torch.cuda.synchronize(device)
             dist.barrier()
             torch.cuda.synchronize(device)
 

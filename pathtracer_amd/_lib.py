@@ -53,6 +53,13 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc, gfx950). There is no CPU fallback.")
+        # PyTorch wheels bundle their own HIP runtime.  When a process uses both (multi-GPU runs use
+        # torch.distributed for RCCL), torch has to be loaded first so that both resolve to one runtime;
+        # loaded the other way round torch later reports "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

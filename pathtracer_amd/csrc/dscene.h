@@ -61,6 +61,9 @@ struct alignas(16) DNeg {
 #define PT_REF_MASK 0x1FFFFFFFu
 #define PT_SLOT_NONE 0xFFFFFFFFu
 #define PT_SLOT_INF 0x80000000u
+#ifndef PT_LDS_SCENE_MAX
+#define PT_LDS_SCENE_MAX 16384u  // bytes of scene records staged in LDS per workgroup
+#endif
 
 struct DScene {
     const DPrim* prims;       // BVH primitives, leaf order
@@ -77,4 +80,6 @@ struct DScene {
     int32_t sky_tex;          // texture id of the first textured skybox figure, or -1 (skybox.wgsl:9-20)
     float sky_color[3];       // its material base_color
     uint32_t stack_entries;   // traversal stack slots per lane held in LDS (<= 31)
+    uint32_t npair;
+    uint32_t lds_scene_bytes; // > 0: the scene records fit in LDS and the LDS-staged kernel is used
 };

@@ -20,6 +20,9 @@
 
 #define PTX_BLOCK 256
 #define PTX_WAVES_PER_BLOCK 4
+#ifndef PTX_MIN_WAVES
+#define PTX_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
+#endif
 
 struct TraceParams {
     DScene sc;
@@ -51,10 +54,39 @@ PT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_trace_kernel(const TraceParams P) {
+// Cooperative copy of `bytes` (a multiple of 16) from global memory into LDS.
+PT_DEV void copy_to_lds(void* dst, const void* src, uint32_t bytes) {
+    uint4* d = (uint4*)dst;
+    const uint4* s = (const uint4*)src;
+    for (uint32_t i = threadIdx.x; i < bytes / 16u; i += PTX_BLOCK) d[i] = s[i];
+}
+
+// LDS_SCENE: the whole scene (primitives, planes, node pairs, shading records, lights, subtraction
+// shapes) is small enough to be staged in LDS once per workgroup; every later scene read is then an
+// LDS read (~100 cycles) instead of a dependent L1/L2 round trip, which is what the traversal waits on.
+template <bool LDS_SCENE>
+PT_DEV void trace_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     StackEntry* st = lds_stack + (size_t)wave * P.sc.stack_entries * 64u + lane;
+    DScene sc = P.sc;
+    if (LDS_SCENE) {
+        char* base = (char*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.stack_entries * 64u);
+        uint32_t off = 0;
+        auto stage = [&](const void* src, uint32_t bytes) -> void* {
+            void* dst = base + off;
+            copy_to_lds(dst, src, bytes);
+            off += bytes;
+            return dst;
+        };
+        sc.prims = (const DPrim*)stage(P.sc.prims, P.sc.nprim * (uint32_t)sizeof(DPrim));
+        sc.inf = (const DPrim*)stage(P.sc.inf, P.sc.ninf * (uint32_t)sizeof(DPrim));
+        sc.pairs = (const DNodePair*)stage(P.sc.pairs, P.sc.npair * (uint32_t)sizeof(DNodePair));
+        sc.shade = (const DShade*)stage(P.sc.shade, P.sc.nfig * (uint32_t)sizeof(DShade));
+        sc.lights = (const DLight*)stage(P.sc.lights, P.sc.nlight * (uint32_t)sizeof(DLight));
+        sc.negs = (const DNeg*)stage(P.sc.negs, P.sc.nneg * (uint32_t)sizeof(DNeg));
+        __syncthreads();
+    }
 
     const uint32_t blk = xcd_remap(blockIdx.x, P.n_blocks) * P.part_world + P.part_rank;
     const uint32_t bx = blk % P.blocks_x, by = blk / P.blocks_x;
@@ -83,16 +115,22 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_trace_kernel(const T
         ps.rng = pcg_hash(px + py * 65536u + P.first_frame * 16777259u);  // random.wgsl:12-14
         ps.ray = generate_ray(P.cam, ps.rng, (float)px, (float)py);
     }
+#ifdef PTX_PHASE_TIMING
+    for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
+    ps.tick_last = clock64();
+#endif
     while (active) {
         bool done = true;
         if (ps.bounce < P.cam.max_bounces) {
             uint32_t fig;
             n_bounce += 1u;
             const bool first = ps.bounce == 0u;
-            done = bounce_step(P.sc, P.cam, ps, st, fig, n_shadow);
+            done = bounce_step(sc, P.cam, ps, st, fig, n_shadow);
+            PT_TICK(3);
             if (first) primary = fig;
             if (!done && ps.bounce >= P.cam.max_bounces) done = true;
         }
+        PT_TICK(4);
         if (done) {
             // path_trace.wgsl:181 and :44-49
             V3 rad = v3(dm::fmax_(ps.radiance.x, 0.0f), dm::fmax_(ps.radiance.y, 0.0f), dm::fmax_(ps.radiance.z, 0.0f));
@@ -121,7 +159,12 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_trace_kernel(const T
                 active = false;
             }
         }
+        PT_TICK(5);
     }
+#ifdef PTX_PHASE_TIMING
+    if (lane == 0u && P.stats)
+        for (int i = 0; i < 6; i++) atomicAdd(&P.stats[4 + i], (unsigned long long)ps.tick_acc[i]);
+#endif
     if (inside && P.n > 0u) {
         P.accum[pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
         if (P.m2) { P.m2[pix * 3] = m2.x; P.m2[pix * 3 + 1] = m2.y; P.m2[pix * 3 + 2] = m2.z; }
@@ -135,6 +178,9 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_trace_kernel(const T
         atomicAdd(&P.stats[2], (unsigned long long)ss);
     }
 }
+
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_MIN_WAVES) ptx_trace_kernel(const TraceParams P) { trace_body<false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_MIN_WAVES) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true>(P); }
 
 // Chan's parallel update of (mean, M2) with another partial result, then re-tonemap.
 extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* out_rgba8, uint32_t first, uint32_t n_pixels,
@@ -338,8 +384,8 @@ int ptx_create(int device, ptx_ctx** out) {
     ptx_ctx* c = new ptx_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&c->stats, 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->stats, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->stats, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return PTX_ERR_HIP;
     }
@@ -518,6 +564,12 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     memcpy(sc.sky_color, sky_color, 12);
     uint32_t entries = depth + 1;
     sc.stack_entries = entries > 31u ? 31u : entries;
+    sc.npair = (uint32_t)pairs.size();
+    {
+        size_t bytes = dprims.size() * sizeof(DPrim) + dinf.size() * sizeof(DPrim) + pairs.size() * sizeof(DNodePair) +
+                       shade.size() * sizeof(DShade) + dl.size() * sizeof(DLight) + negs.size() * sizeof(DNeg);
+        sc.lds_scene_bytes = bytes <= PT_LDS_SCENE_MAX ? (uint32_t)bytes : 0u;
+    }
     c->sc = sc;
     c->have_scene = true;
     return PTX_OK;
@@ -564,7 +616,7 @@ int ptx_clear(ptx_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->out, 0, n * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ids, 0xFF, n * 4, c->stream));
     if (c->m2) HIP_TRY(c, hipMemsetAsync(c->m2, 0, n * 12, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
     return PTX_OK;
 }
 
@@ -597,7 +649,10 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     int rc;
     if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(ptx_trace_kernel, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
+    if (c->sc.lds_scene_bytes > 0u)
+        hipLaunchKernelGGL(ptx_trace_kernel_lds, dim3(P.n_blocks), dim3(PTX_BLOCK), lds + c->sc.lds_scene_bytes, c->stream, P);
+    else
+        hipLaunchKernelGGL(ptx_trace_kernel, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->pending.push_back({e0, e1});
@@ -679,9 +734,12 @@ int ptx_merge_moments(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, uint3
 
 int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
     if (!c || !out) return PTX_ERR_BAD_ARG;
-    unsigned long long v[4];
+    unsigned long long v[16];
     int rc = read_back(c, v, c->stats, sizeof(v), "ptx_read_stats");
     if (rc) return rc;
+#ifdef PTX_PHASE_TIMING
+    fprintf(stderr, "phase cycles: closest %llu shadeA %llu shadow %llu shadeB %llu loop-rest %llu finalize %llu\n", v[4], v[5], v[6], v[7], v[8], v[9]);
+#endif
     out->paths = v[0]; out->bounces = v[1]; out->shadow_rays = v[2];
     return PTX_OK;
 }

@@ -418,12 +418,27 @@ PT_DEV Ray generate_ray(const ptx_camera& cam, uint32_t& rng, float fx, float fy
     return r;
 }
 
+// Optional per-phase cycle attribution (diagnostic builds only: -DPTX_PHASE_TIMING).
+#ifdef PTX_PHASE_TIMING
+static __device__ __forceinline__ void pt_tick_impl(unsigned long long* acc, unsigned long long& last, int i) {
+    unsigned long long now = clock64();
+    acc[i] += now - last;
+    last = now;
+}
+#define PT_TICK(i) pt_tick_impl(ps.tick_acc, ps.tick_last, i)
+#else
+#define PT_TICK(i)
+#endif
+
 // One iteration of the bounce loop of path_trace.wgsl:63-179 for this lane.  Returns true when the
 // path has ended (radiance final).  `primary` receives the figure index of the closest hit.
 struct PathState {
     Ray ray;
     V3 throughput, radiance;
     uint32_t rng, bounce;
+#ifdef PTX_PHASE_TIMING
+    unsigned long long tick_acc[6], tick_last;
+#endif
 };
 PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, StackEntry* st, uint32_t& hit_fig,
                         uint32_t& n_shadow) {
@@ -432,6 +447,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     float t;
     uint32_t slot;
     trace_closest(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot);
+    PT_TICK(0);
     if (slot == PT_SLOT_NONE) {
         hit_fig = 0xFFFFFFFFu;
         ps.radiance = ps.radiance + ps.throughput * sample_skybox(sc, cam, ps.ray.d);
@@ -497,7 +513,10 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
                 sray.o = madd(h.pos, n, PT_EPS * 2.0f);
                 sray.d = light_dir;
                 n_shadow += 1u;
-                if (!trace_shadow(sc, sray, light_dist, cam.fractal_march_steps, st)) {
+                PT_TICK(1);
+                bool occluded = trace_shadow(sc, sray, light_dist, cam.fractal_march_steps, st);
+                PT_TICK(2);
+                if (!occluded) {
                     V3 light_normal = normalize(light_point - lpos);
                     float cos_light = dm::abs_(dot(-light_dir, light_normal));
                     float light_solid_pdf = cos_light <= 0.0f ? 0.0f : L.area_pdf * (light_dist * light_dist) / cos_light;

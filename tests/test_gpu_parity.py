@@ -301,20 +301,25 @@ def test_sample_split_chan_merge_matches_single_run_within_tolerance(pt):
         pt.clear()
         pt.trace_n(cam, first, 1, cnt)
         parts.append((cnt, pt.read_accum(), pt.read_moments()))
-    # device merge: partial 0 is the accumulator, 1 and 2 are folded in through ptx_merge_moments
-    import torch
-    dev = torch.device("cuda:0")
+    # device merge: partial 0 is the accumulator; partials 1 and 2 are rendered by a second context (as
+    # another GPU's would be) and folded in through ptx_merge_moments from its device buffers
+    other = PathTracer(0)
+    _upload(other, sb)
+    other.enable_moments(True)
+    other.resize(w, h)
     pt.clear()
     pt.trace_n(cam, 0, 1, parts[0][0])
     n_a = parts[0][0]
     cn, cm, cm2 = parts[0][0], parts[0][1][..., :3].copy(), parts[0][2].copy()
-    for cnt, acc, m2 in parts[1:]:
-        ta, tm = torch.from_numpy(acc).to(dev), torch.from_numpy(m2).to(dev)
-        torch.cuda.synchronize()
-        pt.merge_moments(0, w * h, n_a, ta.data_ptr(), tm.data_ptr(), cnt, cam)
+    for (first, cnt), (_, acc, m2) in zip(sample_ranges(total, 3)[1:], parts[1:]):
+        other.clear()
+        other.trace_n(cam, first, 1, cnt)
+        other.sync()
+        pt.merge_moments(0, w * h, n_a, other.device_accum_ptr(), other.device_moments_ptr(), cnt, cam)
         pt.sync()
         n_a += cnt
         cn, cm, cm2 = chan_merge(cn, cm, cm2, cnt, acc[..., :3], m2)
+    other.close()
     got_mean, got_m2 = pt.read_accum()[..., :3], pt.read_moments()
     assert same_bits(got_mean, cm) == 0 and same_bits(got_m2, cm2) == 0  # device merge == numpy merge, bitwise
     # merged vs sequential: rounding only.  Tolerance 1e-5 relative to the pixel's scale.

@@ -1,0 +1,34 @@
+"""Quick throughput probe of the trace kernel on the four configuration scenes (GPU box)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pathtracer_amd import host, _lib  # noqa: E402
+if os.environ.get("PTX355_LIB"):  # A/B of differently built libraries
+    _lib.LIB_PATH = os.path.abspath(os.environ["PTX355_LIB"])
+from pathtracer_amd.device import PathTracer  # noqa: E402
+
+CASES = [("cornell_box", 1920, 1080, (32, 128)), ("teapot", 3840, 2160, (8,)), ("fractals", 1920, 1080, (2,)), ("all", 1920, 1080, (16,))]
+print("library:", _lib.LIB_PATH)
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if c[0] in sys.argv[1:]]
+pt = PathTracer(0)
+for name, w, h, ns in CASES:
+    sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
+    cam = sc.camera(w, h)
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, 1)
+    pt.sync()
+    pt.kernel_time()
+    for n in ns:
+        pt.clear()
+        pt.sync()
+        pt.trace_n(cam, 0, 1, n)
+        pt.sync()
+        ms, _ = pt.kernel_time()
+        st = pt.stats()
+        print(f"{name} {w}x{h} n={n}: kernel {ms:.1f} ms  {w * h * n / ms / 1e3:.1f} Mpaths/s  {st['bounces'] / ms / 1e6:.3f} Gpath-bounce/s  "
+              f"bounces/path {st['bounces'] / st['paths']:.2f} shadow/path {st['shadow_rays'] / st['paths']:.2f}", flush=True)
