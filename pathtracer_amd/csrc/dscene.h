@@ -81,5 +81,6 @@ struct DScene {
     float sky_color[3];       // its material base_color
     uint32_t stack_entries;   // traversal stack slots per lane held in LDS (<= 31)
     uint32_t npair;
+    uint32_t has_fractals;    // any Mandelbulb / Julia figure in the BVH: selects the kernel variant with their marchers
     uint32_t lds_scene_bytes; // > 0: the scene records fit in LDS and the LDS-staged kernel is used
 };

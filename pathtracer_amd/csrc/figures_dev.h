@@ -584,18 +584,25 @@ PT_DEV float sdf_julia(V3 p, V4 cc, int max_iter) {  // julia.wgsl:13-32
 }
 
 // Evaluates the figure's distance field at a point given in the space its marcher steps in.
+// FRAC: the kernel variant is compiled with the Mandelbulb / Julia marchers.  Scenes without fractal
+// figures run a variant without them: their register footprint alone costs a wave of occupancy.
+template <bool FRAC>
 PT_DEV float sdf_eval(const DPrim& g, V3 p) {
-    switch (g.type) {
-        case FIG_TORUS: return sdf_torus(p, g.p[3], g.p[4]);
-        case FIG_MEBIUS: return sdf_mebius(p, g.p[3]);
-        case FIG_MANDELBULB: return sdf_mandelbulb(p, g.p[4], (int)g.p[5]);
-        default: { V4 c; c.x = g.p[5]; c.y = g.p[6]; c.z = g.p[7]; c.w = g.p[8]; return sdf_julia(p, c, (int)g.p[4]); }
+    if (g.type == FIG_TORUS) return sdf_torus(p, g.p[3], g.p[4]);
+    if (g.type == FIG_MEBIUS) return sdf_mebius(p, g.p[3]);
+    if (FRAC) {
+        if (g.type == FIG_MANDELBULB) return sdf_mandelbulb(p, g.p[4], (int)g.p[5]);
+        V4 c; c.x = g.p[5]; c.y = g.p[6]; c.z = g.p[7]; c.w = g.p[8];
+        return sdf_julia(p, c, (int)g.p[4]);
     }
+    return 0.0f;
 }
 // Tetrahedron normal: offsets e.xyy, e.yyx, e.yxy, e.xxx with e = (k, -k)  (torus.wgsl:54-61 etc.)
+template <bool FRAC>
 PT_DEV V3 tet_normal(const DPrim& g, V3 local, float k) {
     V3 o0 = v3(k, -k, -k), o1 = v3(-k, -k, k), o2 = v3(-k, k, -k), o3 = v3(k, k, k);
-    float d0 = sdf_eval(g, local + o0), d1 = sdf_eval(g, local + o1), d2 = sdf_eval(g, local + o2), d3 = sdf_eval(g, local + o3);
+    float d0 = sdf_eval<FRAC>(g, local + o0), d1 = sdf_eval<FRAC>(g, local + o1), d2 = sdf_eval<FRAC>(g, local + o2),
+          d3 = sdf_eval<FRAC>(g, local + o3);
     return normalize(o0 * d0 + o1 * d1 + o2 * d2 + o3 * d3);
 }
 // torus.wgsl:10-81
@@ -636,7 +643,7 @@ PT_DEV void finish_torus(const Ray& ray, const DPrim& g, float t, HitFull* h, bo
     V3 pos = v3p(g.p);
     h->pos = madd(ray.o, ray.d, t);
     V3 local = h->pos - pos;
-    h->normal = tet_normal(g, local, 0.5773f * PT_EPS);
+    h->normal = tet_normal<false>(g, local, 0.5773f * PT_EPS);
     if (need_uv) {
         float angle_major = dm::atan2_(local.z, local.x);
         float px = dm::sqrt_(dot2(local.x, local.z, local.x, local.z)) - g.p[3];
@@ -671,7 +678,7 @@ PT_DEV void finish_mebius(const Ray& ray, const DPrim& g, float t, HitFull* h, b
     V3 pos = v3p(g.p);
     h->pos = madd(ray.o, ray.d, t);
     V3 local = h->pos - pos;
-    h->normal = tet_normal(g, local, 0.5773f * PT_EPS * 2.0f);
+    h->normal = tet_normal<false>(g, local, 0.5773f * PT_EPS * 2.0f);
     if (need_uv) {
         float angle = dm::atan2_(local.z, local.x);
         h->uv.x = angle / PT_TWO_PI + 0.5f;
@@ -695,11 +702,11 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
     float prev_d = 0.0f;
     for (uint32_t i = 0; i < march_steps; i++) {
         V3 p = madd(ray.o, ray.d, t) - pos;
-        float d = sdf_eval(g, p / radius) * radius;
+        float d = sdf_eval<true>(g, p / radius) * radius;
         if (d < 0.0f && prev_d > 0.0f) {
             t -= prev_d * (omega - 1.0f);
             V3 p2 = madd(ray.o, ray.d, t) - pos;
-            float d2 = sdf_eval(g, p2 / radius) * radius;
+            float d2 = sdf_eval<true>(g, p2 / radius) * radius;
             t += d2;
             prev_d = d2;
             continue;
@@ -715,12 +722,13 @@ PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) 
     V3 pos = v3p(g.p);
     h->pos = madd(ray.o, ray.d, t);
     V3 local = (h->pos - pos) / g.p[3];
-    h->normal = tet_normal(g, local, 0.5773f * PT_EPS * 2.0f);
+    h->normal = tet_normal<true>(g, local, 0.5773f * PT_EPS * 2.0f);
     h->uv.x = 0.0f;
     h->uv.y = 0.0f;
 }
 
 // Candidate test: hit distance only (figures/dispatch.wgsl:22-89).
+template <bool FRAC>
 PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t march_steps, float& t) {
     switch (g.type) {
         case FIG_SPHERE: return isect_sphere<false>(ray, g, t, nullptr, false);
@@ -733,7 +741,7 @@ PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t mar
         case FIG_TRIANGLE: return isect_triangle<false>(ray, g, t, nullptr, false, nullptr);
         case FIG_SKYBOX: return isect_skybox<false>(ray, g, t, nullptr, false);
         case FIG_MANDELBULB:
-        case FIG_JULIA: return march_fractal(ray, g, march_steps, t);
+        case FIG_JULIA: if (FRAC) return march_fractal(ray, g, march_steps, t); return false;
         case FIG_ELLIPSOID: return isect_ellipsoid<false>(ray, g, t, nullptr, false);
         case FIG_PARABOLOID: return isect_paraboloid<false>(ray, g, t, nullptr, false);
         case FIG_HYPERBOLOID: return isect_hyperboloid<false>(ray, g, t, nullptr, false);
@@ -744,6 +752,7 @@ PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t mar
     }
 }
 // Winner resolution: position, normal and (when the material is textured) UV of the hit at distance t.
+template <bool FRAC>
 PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, bool need_uv, const DShade* sh, HitFull* h) {
     float tt;
     h->uv.x = 0.0f;
@@ -759,7 +768,7 @@ PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, boo
         case FIG_TRIANGLE: isect_triangle<true>(ray, g, tt, h, need_uv, sh); break;
         case FIG_SKYBOX: isect_skybox<true>(ray, g, tt, h, need_uv); break;
         case FIG_MANDELBULB:
-        case FIG_JULIA: finish_fractal(ray, g, t, h); break;
+        case FIG_JULIA: if (FRAC) finish_fractal(ray, g, t, h); break;
         case FIG_ELLIPSOID: isect_ellipsoid<true>(ray, g, tt, h, need_uv); break;
         case FIG_PARABOLOID: isect_paraboloid<true>(ray, g, tt, h, need_uv); break;
         case FIG_HYPERBOLOID: isect_hyperboloid<true>(ray, g, tt, h, need_uv); break;

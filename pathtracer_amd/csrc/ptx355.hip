@@ -20,6 +20,7 @@
 
 #define PTX_BLOCK 256
 #define PTX_WAVES_PER_BLOCK 4
+#define PT_PIXEL_FIELDS 9u  // per-lane LDS slots: mean xyz, M2 xyz, sample index, path-bounces, primary id
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
@@ -64,14 +65,14 @@ PT_DEV void copy_to_lds(void* dst, const void* src, uint32_t bytes) {
 // LDS_SCENE: the whole scene (primitives, planes, node pairs, shading records, lights, subtraction
 // shapes) is small enough to be staged in LDS once per workgroup; every later scene read is then an
 // LDS read (~100 cycles) instead of a dependent L1/L2 round trip, which is what the traversal waits on.
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool FRAC>
 PT_DEV void trace_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     StackEntry* st = lds_stack + (size_t)wave * P.sc.stack_entries * 64u + lane;
     DScene sc = P.sc;
     if (LDS_SCENE) {
-        char* base = (char*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.stack_entries * 64u);
+        char* base = (char*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.stack_entries * 64u) + (size_t)PTX_WAVES_PER_BLOCK * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u * 4u;
         uint32_t off = 0;
         auto stage = [&](const void* src, uint32_t bytes) -> void* {
             void* dst = base + off;
@@ -96,14 +97,25 @@ PT_DEV void trace_body(const TraceParams& P) {
     const uint32_t px = P.tile_x0 + tx, py = P.tile_y0 + ty;
     const size_t pix = (size_t)py * P.cam.width + px;
 
-    V3 mean = v3(0.0f, 0.0f, 0.0f), m2 = v3(0.0f, 0.0f, 0.0f);
+    // Per-pixel state that is only touched when a path ends (running mean, M2, sample index, tallies)
+    // lives in LDS, one lane-interleaved slot per field, so it does not occupy registers during traversal.
+    float* px_f = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.stack_entries * 64u) + (size_t)wave * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u + lane;
+    uint32_t* px_u = (uint32_t*)px_f;
     bool active = inside && P.n > 0u;
-    if (active) {
-        float4 a = P.accum[pix];
-        mean = v3(a.x, a.y, a.z);
-        if (P.m2) m2 = v3(P.m2[pix * 3], P.m2[pix * 3 + 1], P.m2[pix * 3 + 2]);
+    {
+        V3 mean = v3(0.0f, 0.0f, 0.0f), m2 = v3(0.0f, 0.0f, 0.0f);
+        if (active) {
+            float4 a = P.accum[pix];
+            mean = v3(a.x, a.y, a.z);
+            if (P.m2) m2 = v3(P.m2[pix * 3], P.m2[pix * 3 + 1], P.m2[pix * 3 + 2]);
+        }
+        px_f[0 * 64] = mean.x; px_f[1 * 64] = mean.y; px_f[2 * 64] = mean.z;
+        px_f[3 * 64] = m2.x; px_f[4 * 64] = m2.y; px_f[5 * 64] = m2.z;
+        px_u[6 * 64] = 0u;            // k: samples finished
+        px_u[7 * 64] = 0u;            // path-bounces
+        px_u[8 * 64] = 0xFFFFFFFFu;   // primary hit of the latest sample
     }
-    uint32_t k = 0, n_bounce = 0, n_shadow = 0, primary = 0xFFFFFFFFu;
+    uint32_t n_shadow = 0;
     PathState ps;
     ps.rng = 0u;
     ps.bounce = 0u;
@@ -119,38 +131,45 @@ PT_DEV void trace_body(const TraceParams& P) {
     for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
     ps.tick_last = clock64();
 #endif
+    uint32_t local_bounces = 0;
     while (active) {
         bool done = true;
         if (ps.bounce < P.cam.max_bounces) {
             uint32_t fig;
-            n_bounce += 1u;
+            local_bounces += 1u;
             const bool first = ps.bounce == 0u;
-            done = bounce_step(sc, P.cam, ps, st, fig, n_shadow);
+            done = bounce_step<FRAC>(sc, P.cam, ps, st, px_f + PT_PIXEL_FIELDS * 64u, fig, n_shadow);
             PT_TICK(3);
-            if (first) primary = fig;
+            if (first) px_u[8 * 64] = fig;
             if (!done && ps.bounce >= P.cam.max_bounces) done = true;
         }
         PT_TICK(4);
         if (done) {
             // path_trace.wgsl:181 and :44-49
+            const uint32_t k = px_u[6 * 64];
+            V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
             V3 rad = v3(dm::fmax_(ps.radiance.x, 0.0f), dm::fmax_(ps.radiance.y, 0.0f), dm::fmax_(ps.radiance.z, 0.0f));
             float nn = dm::fmax_((float)(P.first_sample + k), 1.0f);
             V3 delta = rad - mean;
             V3 nm = mean + delta / nn;
             if (P.m2) {
                 V3 d2 = rad - nm;
-                m2 = v3(dm::fma_(delta.x, d2.x, m2.x), dm::fma_(delta.y, d2.y, m2.y), dm::fma_(delta.z, d2.z, m2.z));
+                px_f[3 * 64] = dm::fma_(delta.x, d2.x, px_f[3 * 64]);
+                px_f[4 * 64] = dm::fma_(delta.y, d2.y, px_f[4 * 64]);
+                px_f[5 * 64] = dm::fma_(delta.z, d2.z, px_f[5 * 64]);
             }
-            mean = nm;
+            px_f[0 * 64] = nm.x; px_f[1 * 64] = nm.y; px_f[2 * 64] = nm.z;
             if (P.dbg_radiance && k < P.dbg_capacity) {
                 size_t r = ((size_t)k * P.tile_h * P.tile_w + (size_t)ty * P.tile_w + tx) * 3;
                 P.dbg_radiance[r] = rad.x;
                 P.dbg_radiance[r + 1] = rad.y;
                 P.dbg_radiance[r + 2] = rad.z;
             }
-            k += 1u;
-            if (k < P.n) {
-                ps.rng = pcg_hash(px + py * 65536u + (P.first_frame + k) * 16777259u);
+            px_u[6 * 64] = k + 1u;
+            px_u[7 * 64] += local_bounces;
+            local_bounces = 0u;
+            if (k + 1u < P.n) {
+                ps.rng = pcg_hash(px + py * 65536u + (P.first_frame + k + 1u) * 16777259u);
                 ps.ray = generate_ray(P.cam, ps.rng, (float)px, (float)py);
                 ps.throughput = v3(1.0f, 1.0f, 1.0f);
                 ps.radiance = v3(0.0f, 0.0f, 0.0f);
@@ -166,11 +185,13 @@ PT_DEV void trace_body(const TraceParams& P) {
         for (int i = 0; i < 6; i++) atomicAdd(&P.stats[4 + i], (unsigned long long)ps.tick_acc[i]);
 #endif
     if (inside && P.n > 0u) {
+        V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
         P.accum[pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
-        if (P.m2) { P.m2[pix * 3] = m2.x; P.m2[pix * 3 + 1] = m2.y; P.m2[pix * 3 + 2] = m2.z; }
+        if (P.m2) { P.m2[pix * 3] = px_f[3 * 64]; P.m2[pix * 3 + 1] = px_f[4 * 64]; P.m2[pix * 3 + 2] = px_f[5 * 64]; }
         P.out_rgba8[pix] = tonemap_rgba8(P.cam, mean);
-        P.primary_ids[pix] = primary;
+        P.primary_ids[pix] = px_u[8 * 64];
     }
+    const uint32_t k = px_u[6 * 64], n_bounce = px_u[7 * 64];
     uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow), sp = wave_sum(k);
     if (lane == 0u && P.stats) {
         atomicAdd(&P.stats[0], (unsigned long long)sp);
@@ -179,8 +200,12 @@ PT_DEV void trace_body(const TraceParams& P) {
     }
 }
 
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_MIN_WAVES) ptx_trace_kernel(const TraceParams P) { trace_body<false>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_MIN_WAVES) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true>(P); }
+// Four variants: scene records in global memory or staged in LDS; with or without the fractal marchers.
+// Without them the kernel fits 128 VGPRs (4 waves per SIMD); with them 3 waves.
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true>(P); }
 
 // Chan's parallel update of (mean, M2) with another partial result, then re-tonemap.
 extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* out_rgba8, uint32_t first, uint32_t n_pixels,
@@ -242,10 +267,10 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(con
     Ray r2 = ray;
     float t;
     uint32_t slot;
-    trace_closest(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot);
+    trace_closest<true>(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot);
     hit_id[i] = slot == PT_SLOT_NONE ? 0xFFFFFFFFu : slot_prim(sc, slot).fig;
     hit_t[i] = slot == PT_SLOT_NONE ? PT_MAX_T : t;
-    if (shadow && max_t) shadow[i] = trace_shadow(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;
+    if (shadow && max_t) shadow[i] = trace_shadow<true>(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;
 }
 
 // ================================================================================================
@@ -565,6 +590,9 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     uint32_t entries = depth + 1;
     sc.stack_entries = entries > 31u ? 31u : entries;
     sc.npair = (uint32_t)pairs.size();
+    sc.has_fractals = 0u;
+    for (const DPrim& g : dprims)
+        if (g.type == FIG_MANDELBULB || g.type == FIG_JULIA) sc.has_fractals = 1u;
     {
         size_t bytes = dprims.size() * sizeof(DPrim) + dinf.size() * sizeof(DPrim) + pairs.size() * sizeof(DNodePair) +
                        shade.size() * sizeof(DShade) + dl.size() * sizeof(DLight) + negs.size() * sizeof(DNeg);
@@ -643,16 +671,20 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     P.m2 = c->moments ? c->m2 : nullptr;
     P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;
     P.stats = c->stats;
-    size_t lds = (size_t)PTX_WAVES_PER_BLOCK * c->sc.stack_entries * 64u * sizeof(StackEntry);
+    size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
     if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
     hipEvent_t e0, e1;
     int rc;
     if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    if (c->sc.lds_scene_bytes > 0u)
-        hipLaunchKernelGGL(ptx_trace_kernel_lds, dim3(P.n_blocks), dim3(PTX_BLOCK), lds + c->sc.lds_scene_bytes, c->stream, P);
-    else
-        hipLaunchKernelGGL(ptx_trace_kernel, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
+    const bool frac = c->sc.has_fractals != 0u;
+    if (c->sc.lds_scene_bytes > 0u) {
+        if (frac) hipLaunchKernelGGL(ptx_trace_kernel_lds_frac, dim3(P.n_blocks), dim3(PTX_BLOCK), lds + c->sc.lds_scene_bytes, c->stream, P);
+        else hipLaunchKernelGGL(ptx_trace_kernel_lds, dim3(P.n_blocks), dim3(PTX_BLOCK), lds + c->sc.lds_scene_bytes, c->stream, P);
+    } else {
+        if (frac) hipLaunchKernelGGL(ptx_trace_kernel_frac, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
+        else hipLaunchKernelGGL(ptx_trace_kernel, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->pending.push_back({e0, e1});

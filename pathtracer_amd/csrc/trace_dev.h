@@ -29,6 +29,7 @@ PT_DEV float intersect_aabb(V3 o, V3 inv_dir, const float* bmin, const float* bm
 typedef uint2 StackEntry;
 
 // Closest hit over non-subtracted figures (bvh.wgsl:236-305): distance and primitive slot.
+template <bool FRAC>
 PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
                            float& t_best, uint32_t& slot_best) {
     t_best = PT_MAX_T;
@@ -53,7 +54,7 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
                 for (uint32_t i = 0; i < cnt; i++) {
                     const DPrim& g = sc.prims[ref + i];
                     float ht;
-                    if (g.type != FIG_SKIP && intersect_t(ray, inv_dir, g, march_steps, ht) && ht < t_best && ht > PT_EPS) {
+                    if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht < t_best && ht > PT_EPS) {
                         t_best = ht;
                         slot_best = ref + i;
                     }
@@ -85,7 +86,7 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
     for (uint32_t i = 0; i < sc.ninf; i++) {
         const DPrim& g = sc.inf[i];
         float ht;
-        if (intersect_t(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_best) {
+        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_best) {
             t_best = ht;
             slot_best = PT_SLOT_INF | i;
         }
@@ -184,8 +185,9 @@ PT_DEV const DPrim& slot_prim(const DScene& sc, uint32_t slot) {
     return (slot & PT_SLOT_INF) ? sc.inf[slot & ~PT_SLOT_INF] : sc.prims[slot];
 }
 // bvh.wgsl:143-188.  `ray` is updated to the ray that produced the final hit (its local distance t).
+template <bool FRAC>
 PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st, float& t, uint32_t& slot) {
-    trace_positive(sc, ray, inv_dir, march_steps, st, t, slot);
+    trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot);
     if (sc.nneg > 0u && slot != PT_SLOT_NONE) {
         for (uint32_t attempt = 0; attempt < 8u; attempt++) {
             V3 hp = madd(ray.o, ray.d, t);
@@ -196,13 +198,14 @@ PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march
             if (min_exit >= PT_MAX_T) break;
             float advance = min_exit + PT_EPS * 2.0f;
             ray.o = madd(ray.o, ray.d, advance);
-            trace_positive(sc, ray, inv_dir, march_steps, st, t, slot);
+            trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot);
             if (slot == PT_SLOT_NONE) break;
         }
     }
 }
 
 // Any-hit occlusion (bvh.wgsl:308-362).
+template <bool FRAC>
 PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
     V3 inv_dir = vrcp(ray.d);
     const float t_lim = max_t - PT_EPS;
@@ -217,7 +220,7 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
                     for (uint32_t i = 0; i < cnt; i++) {
                         const DPrim& g = sc.prims[ref + i];
                         float ht;
-                        if (g.type != FIG_SKIP && intersect_t(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_lim)
+                        if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_lim)
                             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
                     }
                 } else {
@@ -246,7 +249,7 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
     for (uint32_t i = 0; i < sc.ninf; i++) {  // bvh.wgsl:212-232
         const DPrim& g = sc.inf[i];
         float ht;
-        if (intersect_t(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_lim)
+        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_lim)
             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
     }
     return false;
@@ -440,13 +443,24 @@ struct PathState {
     unsigned long long tick_acc[6], tick_last;
 #endif
 };
-PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, StackEntry* st, uint32_t& hit_fig,
+#define PT_PARK_FIELDS 23u  // per-lane LDS slots for values parked across the occlusion query
+template <bool FRAC>
+PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, StackEntry* st, float* park, uint32_t& hit_fig,
                         uint32_t& n_shadow) {
     Ray ray = ps.ray;
     V3 inv_dir = vrcp(ray.d);
     float t;
     uint32_t slot;
-    trace_closest(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot);
+    // Path state is parked in LDS while the traversal runs (it is not read there).
+    park[14 * 64] = ps.throughput.x; park[15 * 64] = ps.throughput.y; park[16 * 64] = ps.throughput.z;
+    park[17 * 64] = ps.radiance.x; park[18 * 64] = ps.radiance.y; park[19 * 64] = ps.radiance.z;
+    park[21 * 64] = __uint_as_float(ps.rng);
+    park[22 * 64] = __uint_as_float(ps.bounce);
+    trace_closest<FRAC>(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot);
+    ps.throughput = v3(park[14 * 64], park[15 * 64], park[16 * 64]);
+    ps.radiance = v3(park[17 * 64], park[18 * 64], park[19 * 64]);
+    ps.rng = __float_as_uint(park[21 * 64]);
+    ps.bounce = __float_as_uint(park[22 * 64]);
     PT_TICK(0);
     if (slot == PT_SLOT_NONE) {
         hit_fig = 0xFFFFFFFFu;
@@ -459,7 +473,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     const ptx_material mt = sh.mat;
     bool need_uv = mt.texture_id >= 0;
     HitFull h;
-    resolve_hit(ray, inv_dir, g, t, need_uv, &sh, &h);
+    resolve_hit<FRAC>(ray, inv_dir, g, t, need_uv, &sh, &h);
     V3 base_color = v3p(mt.base_color);
     if (need_uv) {
         V2 tuv;
@@ -489,6 +503,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     mat.metallic = mt.metallic;
     mat.roughness = mt.roughness;
     mat.ior = mt.ior;
+    V3 hpos = h.pos;
     if (mt.roughness > 0.04f) {  // path_trace.wgsl:108-154
         const uint32_t num_lights = sc.nlight > 0u ? sc.nlight : 1u;  // empty list = one-element placeholder
         float pick = rand_f32(ps.rng);
@@ -504,37 +519,60 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
             V3 local_point = v3(sin_theta * cp, sin_theta * sp, cos_theta) * L.radius;
             V3 lpos = v3p(L.pos);
             V3 light_point = lpos + local_point;
-            V3 to_light = light_point - h.pos;
+            V3 to_light = light_point - hpos;
             float light_dist = length(to_light);
             V3 light_dir = to_light / light_dist;
             float n_dot_l = dot(n, light_dir);
             if (n_dot_l > 0.0f) {
+                // The unoccluded contribution is a pure function of values known here; it is evaluated
+                // before the occlusion query so that only it and the BSDF inputs (parked in LDS) stay
+                // live across the traversal.
+                V3 light_normal = normalize(light_point - lpos);
+                float cos_light = dm::abs_(dot(-light_dir, light_normal));
+                float light_solid_pdf = cos_light <= 0.0f ? 0.0f : L.area_pdf * (light_dist * light_dist) / cos_light;
+                V3 brdf = eval_brdf(wo, light_dir, n, mat);
+                float brdf_pdf_val = n_dot_l * PT_INV_PI;
+                float pa = light_solid_pdf * (float)num_lights;
+                float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
+                float w = a2 / dm::fmax_(a2 + b2, 1e-10f);
+                V3 contrib = ps.throughput * v3p(L.le) * brdf * n_dot_l * w / pa;
+                const bool lit = light_solid_pdf > 0.0f;
                 Ray sray;
-                sray.o = madd(h.pos, n, PT_EPS * 2.0f);
+                sray.o = madd(hpos, n, PT_EPS * 2.0f);
                 sray.d = light_dir;
                 n_shadow += 1u;
+                park[0 * 64] = hpos.x; park[1 * 64] = hpos.y; park[2 * 64] = hpos.z;
+                park[3 * 64] = n.x; park[4 * 64] = n.y; park[5 * 64] = n.z;
+                park[6 * 64] = mat.base_color.x; park[7 * 64] = mat.base_color.y; park[8 * 64] = mat.base_color.z;
+                park[9 * 64] = mat.metallic; park[10 * 64] = mat.roughness;
+                park[11 * 64] = contrib.x; park[12 * 64] = contrib.y; park[13 * 64] = contrib.z;
+                park[20 * 64] = lit ? 1.0f : 0.0f;
+                park[21 * 64] = __uint_as_float(ps.rng);
+                park[22 * 64] = __uint_as_float(ps.bounce);
+                park[14 * 64] = ps.throughput.x; park[15 * 64] = ps.throughput.y; park[16 * 64] = ps.throughput.z;
+                park[17 * 64] = ps.radiance.x; park[18 * 64] = ps.radiance.y; park[19 * 64] = ps.radiance.z;
                 PT_TICK(1);
-                bool occluded = trace_shadow(sc, sray, light_dist, cam.fractal_march_steps, st);
+                bool occluded = trace_shadow<FRAC>(sc, sray, light_dist, cam.fractal_march_steps, st);
                 PT_TICK(2);
-                if (!occluded) {
-                    V3 light_normal = normalize(light_point - lpos);
-                    float cos_light = dm::abs_(dot(-light_dir, light_normal));
-                    float light_solid_pdf = cos_light <= 0.0f ? 0.0f : L.area_pdf * (light_dist * light_dist) / cos_light;
-                    V3 brdf = eval_brdf(wo, light_dir, n, mat);
-                    float brdf_pdf_val = n_dot_l * PT_INV_PI;
-                    float pa = light_solid_pdf * (float)num_lights;
-                    float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
-                    float w = a2 / dm::fmax_(a2 + b2, 1e-10f);
-                    if (light_solid_pdf > 0.0f)
-                        ps.radiance = ps.radiance + ps.throughput * v3p(L.le) * brdf * n_dot_l * w / pa;
-                }
+                hpos = v3(park[0 * 64], park[1 * 64], park[2 * 64]);
+                n = v3(park[3 * 64], park[4 * 64], park[5 * 64]);
+                mat.base_color = v3(park[6 * 64], park[7 * 64], park[8 * 64]);
+                mat.metallic = park[9 * 64];
+                mat.roughness = park[10 * 64];
+                ps.throughput = v3(park[14 * 64], park[15 * 64], park[16 * 64]);
+                ps.radiance = v3(park[17 * 64], park[18 * 64], park[19 * 64]);
+                ps.rng = __float_as_uint(park[21 * 64]);
+                ps.bounce = __float_as_uint(park[22 * 64]);
+                wo = -ps.ray.d;
+                if (!occluded && park[20 * 64] != 0.0f)  // path_trace.wgsl:148: only when light_solid_pdf > 0
+                    ps.radiance = ps.radiance + v3(park[11 * 64], park[12 * 64], park[13 * 64]);
             }
         }
     }
     V3 wi, weight;
     if (!sample_brdf(ps.rng, wo, n, mat, wi, weight)) return true;
     ps.throughput = ps.throughput * weight;
-    ps.ray.o = madd(h.pos, wi, PT_EPS * 2.0f);
+    ps.ray.o = madd(hpos, wi, PT_EPS * 2.0f);
     ps.ray.d = wi;
     if (ps.bounce >= 3u) {  // path_trace.wgsl:166-172
         float survival = dm::fmin_(dm::fmax_(ps.throughput.x, dm::fmax_(ps.throughput.y, ps.throughput.z)), 0.95f);
