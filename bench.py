@@ -153,7 +153,7 @@ def main():
                 cpu, cnt, flops = cpu_baseline(fx_name, w, h, cpu_spp)
                 flops_per_bounce = flops / max(cnt["bounces"], 1)
         avg_ms = kernel_ms / max(launches, 1)
-        roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": "ptx_trace_kernel",
+        roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": pt.kernel_name(),
                 "kernel_avg_ms": round(avg_ms, 3), "launches": launches, "traffic": None}
         if flops_per_bounce is not None:
             flops_per_launch = flops_per_bounce * bounces / max(launches, 1)

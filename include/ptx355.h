@@ -163,6 +163,11 @@ int ptx_merge_moments(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, uin
 
 int ptx_read_stats(ptx_ctx* ctx, ptx_stats* out);
 
+/* Name of the kernel variant ptx_trace* launches for the uploaded scene (scene records staged in LDS or
+ * read from global memory; with or without the fractal marchers); "" before ptx_upload_scene.  For
+ * matching profiler output. */
+const char* ptx_trace_kernel_name(const ptx_ctx* ctx);
+
 /* Sum of the trace kernels' durations (HIP events on the context's stream) and their count since the
  * last call; synchronises. */
 int ptx_kernel_time(ptx_ctx* ctx, float* total_ms, uint32_t* launches);

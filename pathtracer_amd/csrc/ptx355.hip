@@ -764,6 +764,12 @@ int ptx_merge_moments(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, uint3
     return PTX_OK;
 }
 
+const char* ptx_trace_kernel_name(const ptx_ctx* c) {
+    if (!c || !c->have_scene) return "";
+    const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
+    return lds ? (frac ? "ptx_trace_kernel_lds_frac" : "ptx_trace_kernel_lds") : (frac ? "ptx_trace_kernel_frac" : "ptx_trace_kernel");
+}
+
 int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
     if (!c || !out) return PTX_ERR_BAD_ARG;
     unsigned long long v[16];

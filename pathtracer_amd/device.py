@@ -134,6 +134,9 @@ class PathTracer:
         self._ck(self.lib.ptx_read_stats(self.h, C.byref(s)), "ptx_read_stats")
         return {"paths": s.paths, "bounces": s.bounces, "shadow_rays": s.shadow_rays}
 
+    def kernel_name(self) -> str:
+        return self.lib.ptx_trace_kernel_name(self.h).decode()
+
     def kernel_time(self) -> Tuple[float, int]:
         ms, n = C.c_float(), C.c_uint32()
         self._ck(self.lib.ptx_kernel_time(self.h, C.byref(ms), C.byref(n)), "ptx_kernel_time")

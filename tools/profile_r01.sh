@@ -1,16 +1,39 @@
 #!/bin/bash
-# Collects the round's rocprofv3 evidence for the benchmark command on a GPU box.  Each pass is its own
-# run (kernel trace + stats; then one PMC pass per counter group), written under gpurun_out/prof/.
+# Collects the round's rocprofv3 evidence for the benchmark command on a GPU box: kernel trace + stats,
+# then one PMC pass per counter group (each its own run), and writes text summaries under
+# gpurun_out/prof/ for copying into profiles/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
-mkdir -p $OUT
-BENCH="python3 bench.py --steps 2 --warmup 1 --spp-per-step 32 --no-cpu-baseline"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU -d $OUT/pmc_sq1 -o pmc -- $BENCH > $OUT/pmc_sq1.log 2>&1 || { echo "pmc sq1 failed"; tail -5 $OUT/pmc_sq1.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2.log 2>&1 || { echo "pmc sq2 failed"; tail -5 $OUT/pmc_sq2.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $OUT/pmc_write.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm -o pmc -- $BENCH > $OUT/pmc_grbm.log 2>&1 || { echo "pmc grbm failed"; tail -5 $OUT/pmc_grbm.log; exit 1; }
-find $OUT -name "*.csv" | head -40
+rm -rf $OUT; mkdir -p $OUT
+BENCH="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
+run_pmc() { # name counters...
+  local name=$1; shift
+  timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- $BENCH > $OUT/$name.log 2>&1 || { echo "pmc $name failed"; tail -5 $OUT/$name.log; exit 1; }
+}
+run_pmc sq1 SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU
+run_pmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT
+run_pmc fetch FETCH_SIZE
+run_pmc write WRITE_SIZE
+run_pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
+python3 - <<'PY'
+import csv, glob, json, collections
+out = {}
+stats = glob.glob('gpurun_out/prof/trace/**/*kernel_stats.csv', recursive=True)
+rows = []
+for f in stats:
+    rows += list(csv.DictReader(open(f)))
+open('gpurun_out/prof/kernel_stats_summary.txt', 'w').write('\n'.join(','.join(f'{k}={v}' for k, v in r.items()) for r in rows) + '\n')
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob('gpurun_out/prof/*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r['Kernel_Name'].startswith('ptx_trace'):
+            a = agg[(r['Kernel_Name'], r['Counter_Name'])]
+            a[0] += float(r['Counter_Value']); a[1] += 1
+lines = [f'{k[0]},{k[1]},sum={v[0]:.0f},dispatches={v[1]},per_dispatch={v[0]/max(v[1],1):.1f}' for k, v in sorted(agg.items())]
+open('gpurun_out/prof/pmc_summary.txt', 'w').write('\n'.join(lines) + '\n')
+print(open('gpurun_out/prof/kernel_stats_summary.txt').read())
+print('\n'.join(lines))
+PY
