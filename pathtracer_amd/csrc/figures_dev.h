@@ -294,13 +294,14 @@ PT_DEV bool isect_triangle(const Ray& ray, const DPrim& g, float& t_out, HitFull
 }
 // Keep-closest face test of pyramid.wgsl:35-70 / tetrahedron.wgsl:33-68 (normal not ray-facing, uv = (u,v)).
 template <bool FULL>
-PT_DEV void face_test(const Ray& ray, V3 v0, V3 v1, V3 v2, bool& hit, float& best, HitFull* h) {
+PT_DEV void face_test(const Ray& ray, V3 v0, V3 v1, V3 v2, bool& hit, float& best, HitFull* h, uint32_t face, uint32_t& sub) {
     V3 e1 = v1 - v0, e2 = v2 - v0;
     float t, u, v;
     if (!mt_core(ray, v0, e1, e2, t, u, v)) return;
     if (t > PT_EPS && t < best) {
         hit = true;
         best = t;
+        sub = face;
         if (FULL) {
             h->pos = madd(ray.o, ray.d, t);
             h->normal = normalize(cross(e1, e2));
@@ -309,25 +310,35 @@ PT_DEV void face_test(const Ray& ray, V3 v0, V3 v1, V3 v2, bool& hit, float& bes
         }
     }
 }
-template <bool FULL>
-PT_DEV bool isect_pyramid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h) {  // pyramid.wgsl:5-32
+// Vertices of face `f` of the pyramid (pyramid.wgsl:13-29): 0..3 sides, 4..5 base.
+PT_DEV void pyramid_face(const DPrim& g, uint32_t f, V3& a, V3& b, V3& c) {
     V3 base = v3p(g.p);
     float r = g.p[3], hh = g.p[4];
     V3 apex = base + v3(0.0f, hh, 0.0f);
     V3 b0 = base + v3(-r, 0.0f, -r), b1 = base + v3(r, 0.0f, -r), b2 = base + v3(r, 0.0f, r), b3 = base + v3(-r, 0.0f, r);
+    switch (f) {
+        case 0: a = apex; b = b0; c = b1; break;
+        case 1: a = apex; b = b1; c = b2; break;
+        case 2: a = apex; b = b2; c = b3; break;
+        case 3: a = apex; b = b3; c = b0; break;
+        case 4: a = b0; b = b2; c = b1; break;
+        default: a = b0; b = b3; c = b2; break;
+    }
+}
+template <bool FULL>
+PT_DEV bool isect_pyramid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, uint32_t& sub) {  // pyramid.wgsl:5-32
     bool hit = false;
     float best = PT_MAX_T;
-    face_test<FULL>(ray, apex, b0, b1, hit, best, h);
-    face_test<FULL>(ray, apex, b1, b2, hit, best, h);
-    face_test<FULL>(ray, apex, b2, b3, hit, best, h);
-    face_test<FULL>(ray, apex, b3, b0, hit, best, h);
-    face_test<FULL>(ray, b0, b2, b1, hit, best, h);
-    face_test<FULL>(ray, b0, b3, b2, hit, best, h);
+    for (uint32_t f = 0; f < 6u; f++) {
+        V3 a, b, c;
+        pyramid_face(g, f, a, b, c);
+        face_test<FULL>(ray, a, b, c, hit, best, h, f, sub);
+    }
     t_out = best;
     return hit;
 }
-template <bool FULL>
-PT_DEV bool isect_tetrahedron(const Ray& ray, const DPrim& g, float& t_out, HitFull* h) {  // tetrahedron.wgsl:4-31
+// Vertices of face `f` of the tetrahedron (tetrahedron.wgsl:14-28).
+PT_DEV void tetra_face(const DPrim& g, uint32_t f, V3& fa, V3& fb, V3& fc) {
     V3 pos = v3p(g.p);
     float r = g.p[3];
     float a = r * 0.942809f, b = r * 0.333333f, c = r * 0.816497f;
@@ -335,12 +346,22 @@ PT_DEV bool isect_tetrahedron(const Ray& ray, const DPrim& g, float& t_out, HitF
     V3 v1 = pos + v3(a, -b, -c * 0.5f);
     V3 v2 = pos + v3(-a, -b, -c * 0.5f);
     V3 v3_ = pos + v3(0.0f, -b, c);
+    switch (f) {
+        case 0: fa = v0; fb = v1; fc = v2; break;
+        case 1: fa = v0; fb = v2; fc = v3_; break;
+        case 2: fa = v0; fb = v3_; fc = v1; break;
+        default: fa = v1; fb = v3_; fc = v2; break;
+    }
+}
+template <bool FULL>
+PT_DEV bool isect_tetrahedron(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, uint32_t& sub) {  // tetrahedron.wgsl:4-31
     bool hit = false;
     float best = PT_MAX_T;
-    face_test<FULL>(ray, v0, v1, v2, hit, best, h);
-    face_test<FULL>(ray, v0, v2, v3_, hit, best, h);
-    face_test<FULL>(ray, v0, v3_, v1, hit, best, h);
-    face_test<FULL>(ray, v1, v3_, v2, hit, best, h);
+    for (uint32_t f = 0; f < 4u; f++) {
+        V3 a, b, c;
+        tetra_face(g, f, a, b, c);
+        face_test<FULL>(ray, a, b, c, hit, best, h, f, sub);
+    }
     t_out = best;
     return hit;
 }
@@ -728,8 +749,10 @@ PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) 
 }
 
 // Candidate test: hit distance only (figures/dispatch.wgsl:22-89).
+// `sub` receives the winning face of a pyramid / tetrahedron (0 otherwise) for resolve_hit.
 template <bool FRAC>
-PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t march_steps, float& t) {
+PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t march_steps, float& t, uint32_t& sub) {
+    sub = 0u;
     switch (g.type) {
         case FIG_SPHERE: return isect_sphere<false>(ray, g, t, nullptr, false);
         case FIG_PLANE: return isect_plane<false>(ray, g, t, nullptr, false);
@@ -746,35 +769,97 @@ PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t mar
         case FIG_PARABOLOID: return isect_paraboloid<false>(ray, g, t, nullptr, false);
         case FIG_HYPERBOLOID: return isect_hyperboloid<false>(ray, g, t, nullptr, false);
         case FIG_MEBIUS: return march_mebius(ray, g, t);
-        case FIG_PYRAMID: return isect_pyramid<false>(ray, g, t, nullptr);
-        case FIG_TETRAHEDRON: return isect_tetrahedron<false>(ray, g, t, nullptr);
+        case FIG_PYRAMID: return isect_pyramid<false>(ray, g, t, nullptr, sub);
+        case FIG_TETRAHEDRON: return isect_tetrahedron<false>(ray, g, t, nullptr, sub);
         default: return false;
     }
 }
 // Winner resolution: position, normal and (when the material is textured) UV of the hit at distance t.
+// The common closed-form figures are finished directly from t (the same instructions the reference
+// runs after it has found t); a pyramid / tetrahedron from its winning face `sub`; the rest re-run
+// their intersector in FULL mode.  The distance is never recomputed differently, so nothing changes.
+PT_DEV void finish_face(const Ray& ray, V3 a, V3 b, V3 c, float t, bool need_uv, HitFull* h) {
+    V3 e1 = b - a, e2 = c - a;
+    h->pos = madd(ray.o, ray.d, t);
+    h->normal = normalize(cross(e1, e2));
+    if (need_uv) {
+        float tt, u, v;
+        mt_core(ray, a, e1, e2, tt, u, v);
+        h->uv.x = u;
+        h->uv.y = v;
+    }
+}
 template <bool FRAC>
-PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, bool need_uv, const DShade* sh, HitFull* h) {
+PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, uint32_t sub, bool need_uv, const DShade* sh, HitFull* h) {
     float tt;
+    uint32_t s2;
     h->uv.x = 0.0f;
     h->uv.y = 0.0f;
     switch (g.type) {
-        case FIG_SPHERE: isect_sphere<true>(ray, g, tt, h, need_uv); break;
-        case FIG_PLANE: isect_plane<true>(ray, g, tt, h, need_uv); break;
+        case FIG_SPHERE: {
+            V3 pos = v3p(g.p);
+            h->pos = madd(ray.o, ray.d, t);
+            h->normal = normalize(h->pos - pos);
+            if (need_uv) h->uv = sphere_uv(h->normal);
+            break;
+        }
+        case FIG_PLANE: {
+            V3 pos = v3p(g.p), n = v3p(g.p + 3);
+            float denom = dot(n, ray.d);
+            h->pos = madd(ray.o, ray.d, t);
+            h->normal = denom < 0.0f ? n : -n;
+            if (need_uv) {
+                Onb onb = build_onb(h->normal);
+                V3 local = h->pos - pos;
+                h->uv.x = dot(local, onb.u) * 0.25f;
+                h->uv.y = dot(local, onb.v) * 0.25f;
+            }
+            break;
+        }
         case FIG_CUBE: isect_cube<true>(ray, inv_dir, g, tt, h); break;
         case FIG_CYLINDER: isect_cylinder<true>(ray, g, tt, h, need_uv); break;
         case FIG_CONE: isect_cone<true>(ray, g, tt, h, need_uv); break;
         case FIG_TORUS: finish_torus(ray, g, t, h, need_uv); break;
-        case FIG_DISC: isect_disc<true>(ray, g, tt, h); break;
-        case FIG_TRIANGLE: isect_triangle<true>(ray, g, tt, h, need_uv, sh); break;
+        case FIG_DISC: {
+            V3 pos = v3p(g.p), n = v3p(g.p + 3);
+            float radius = g.p[6];
+            float denom = dot(n, ray.d);
+            h->pos = madd(ray.o, ray.d, t);
+            h->normal = denom < 0.0f ? n : -n;
+            if (need_uv) {
+                V3 off = h->pos - pos;
+                h->uv.x = (off.x / radius + 1.0f) * 0.5f;
+                h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+            }
+            break;
+        }
+        case FIG_TRIANGLE: {
+            V3 e1 = v3p(g.p + 3), e2 = v3p(g.p + 6);
+            h->pos = madd(ray.o, ray.d, t);
+            h->normal = normalize(cross(e1, e2));
+            if (dot(h->normal, ray.d) > 0.0f) h->normal = -h->normal;
+            if (need_uv) isect_triangle<true>(ray, g, tt, h, true, sh);
+            break;
+        }
         case FIG_SKYBOX: isect_skybox<true>(ray, g, tt, h, need_uv); break;
         case FIG_MANDELBULB:
         case FIG_JULIA: if (FRAC) finish_fractal(ray, g, t, h); break;
-        case FIG_ELLIPSOID: isect_ellipsoid<true>(ray, g, tt, h, need_uv); break;
+        case FIG_ELLIPSOID: {
+            V3 pos = v3p(g.p);
+            float radius = g.p[3], height = g.p[4], radius2 = g.p[5];
+            V3 inv_radii = vrcp(v3(radius, dm::fmax_(height, radius), dm::fmax_(radius2, radius)));
+            h->pos = madd(ray.o, ray.d, t);
+            V3 local = h->pos - pos;
+            h->normal = normalize(local * inv_radii * inv_radii);
+            if (need_uv) h->uv = sphere_uv(normalize(local * inv_radii));
+            break;
+        }
         case FIG_PARABOLOID: isect_paraboloid<true>(ray, g, tt, h, need_uv); break;
         case FIG_HYPERBOLOID: isect_hyperboloid<true>(ray, g, tt, h, need_uv); break;
         case FIG_MEBIUS: finish_mebius(ray, g, t, h, need_uv); break;
-        case FIG_PYRAMID: isect_pyramid<true>(ray, g, tt, h); break;
-        case FIG_TETRAHEDRON: isect_tetrahedron<true>(ray, g, tt, h); break;
+        case FIG_PYRAMID: { V3 a, b, c; pyramid_face(g, sub, a, b, c); finish_face(ray, a, b, c, t, need_uv, h); break; }
+        case FIG_TETRAHEDRON: { V3 a, b, c; tetra_face(g, sub, a, b, c); finish_face(ray, a, b, c, t, need_uv, h); break; }
         default: h->pos = madd(ray.o, ray.d, t); h->normal = v3(0.0f, 0.0f, 0.0f); break;
     }
+    (void)s2;
 }

@@ -266,8 +266,8 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(con
     ray.d = v3p(rays + 6 * (size_t)i + 3);
     Ray r2 = ray;
     float t;
-    uint32_t slot;
-    trace_closest<true>(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot);
+    uint32_t slot, sub;
+    trace_closest<true>(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot, sub);
     hit_id[i] = slot == PT_SLOT_NONE ? 0xFFFFFFFFu : slot_prim(sc, slot).fig;
     hit_t[i] = slot == PT_SLOT_NONE ? PT_MAX_T : t;
     if (shadow && max_t) shadow[i] = trace_shadow<true>(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;

@@ -31,9 +31,10 @@ typedef uint2 StackEntry;
 // Closest hit over non-subtracted figures (bvh.wgsl:236-305): distance and primitive slot.
 template <bool FRAC>
 PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
-                           float& t_best, uint32_t& slot_best) {
+                           float& t_best, uint32_t& slot_best, uint32_t& sub_best) {
     t_best = PT_MAX_T;
     slot_best = PT_SLOT_NONE;
+    sub_best = 0u;
     if (sc.nprim > 0u) {
         int sp = 0;
         uint32_t cur = sc.root_ref;
@@ -54,9 +55,11 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
                 for (uint32_t i = 0; i < cnt; i++) {
                     const DPrim& g = sc.prims[ref + i];
                     float ht;
-                    if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht < t_best && ht > PT_EPS) {
+                    uint32_t sub;
+                    if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht < t_best && ht > PT_EPS) {
                         t_best = ht;
                         slot_best = ref + i;
+                        sub_best = sub;
                     }
                 }
             } else {
@@ -86,9 +89,11 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
     for (uint32_t i = 0; i < sc.ninf; i++) {
         const DPrim& g = sc.inf[i];
         float ht;
-        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_best) {
+        uint32_t sub;
+        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_best) {
             t_best = ht;
             slot_best = PT_SLOT_INF | i;
+            sub_best = sub;
         }
     }
 }
@@ -186,8 +191,9 @@ PT_DEV const DPrim& slot_prim(const DScene& sc, uint32_t slot) {
 }
 // bvh.wgsl:143-188.  `ray` is updated to the ray that produced the final hit (its local distance t).
 template <bool FRAC>
-PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st, float& t, uint32_t& slot) {
-    trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot);
+PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st, float& t, uint32_t& slot,
+                          uint32_t& sub) {
+    trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
     if (sc.nneg > 0u && slot != PT_SLOT_NONE) {
         for (uint32_t attempt = 0; attempt < 8u; attempt++) {
             V3 hp = madd(ray.o, ray.d, t);
@@ -198,7 +204,7 @@ PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march
             if (min_exit >= PT_MAX_T) break;
             float advance = min_exit + PT_EPS * 2.0f;
             ray.o = madd(ray.o, ray.d, advance);
-            trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot);
+            trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
             if (slot == PT_SLOT_NONE) break;
         }
     }
@@ -220,7 +226,8 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
                     for (uint32_t i = 0; i < cnt; i++) {
                         const DPrim& g = sc.prims[ref + i];
                         float ht;
-                        if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_lim)
+                        uint32_t sub;
+                        if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
                             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
                     }
                 } else {
@@ -249,7 +256,8 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
     for (uint32_t i = 0; i < sc.ninf; i++) {  // bvh.wgsl:212-232
         const DPrim& g = sc.inf[i];
         float ht;
-        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht) && ht > PT_EPS && ht < t_lim)
+        uint32_t sub;
+        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
     }
     return false;
@@ -450,13 +458,13 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     Ray ray = ps.ray;
     V3 inv_dir = vrcp(ray.d);
     float t;
-    uint32_t slot;
+    uint32_t slot, sub;
     // Path state is parked in LDS while the traversal runs (it is not read there).
     park[14 * 64] = ps.throughput.x; park[15 * 64] = ps.throughput.y; park[16 * 64] = ps.throughput.z;
     park[17 * 64] = ps.radiance.x; park[18 * 64] = ps.radiance.y; park[19 * 64] = ps.radiance.z;
     park[21 * 64] = __uint_as_float(ps.rng);
     park[22 * 64] = __uint_as_float(ps.bounce);
-    trace_closest<FRAC>(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot);
+    trace_closest<FRAC>(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot, sub);
     ps.throughput = v3(park[14 * 64], park[15 * 64], park[16 * 64]);
     ps.radiance = v3(park[17 * 64], park[18 * 64], park[19 * 64]);
     ps.rng = __float_as_uint(park[21 * 64]);
@@ -473,7 +481,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     const ptx_material mt = sh.mat;
     bool need_uv = mt.texture_id >= 0;
     HitFull h;
-    resolve_hit<FRAC>(ray, inv_dir, g, t, need_uv, &sh, &h);
+    resolve_hit<FRAC>(ray, inv_dir, g, t, sub, need_uv, &sh, &h);
     V3 base_color = v3p(mt.base_color);
     if (need_uv) {
         V2 tuv;
