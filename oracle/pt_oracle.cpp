@@ -13,7 +13,7 @@
 //   dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))          (dot2/dot4 likewise, low index first)
 //   cross(a,b).x  = fma(a.y,b.z, -(a.z*b.y))   (cyclic)
 //   o + d*t       = fma(d,t,o) per component  ("madd")
-//   length(v)     = sqrt(dot(v,v));  normalize(v) = v * (1/length(v))
+//   length(v)     = sqrt(dot(v,v));  normalize(v) = v * (1/length(v));  vector / scalar = vector * (1/scalar)
 //   mix(a,b,t)    = a*(1-t) + b*t  (unfused);  every other vector expression is unfused, left to right
 //   min/max       = IEEE minNum/maxNum with -0 < +0
 //   sin, cos, atan2, asin, acos, log, pow = oracle/dmath.h
@@ -121,6 +121,8 @@ inline V3 cross(V3 a, V3 b) {
 inline V3 madd(V3 o, V3 d, float t) { return {fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)}; }
 inline float length(V3 a) { return sqrtf(dot(a, a)); }
 inline V3 normalize(V3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+// vector / scalar = vector * (1 / scalar): one correctly rounded reciprocal, then three multiplies.
+inline V3 vdivs(V3 a, float s) { float inv = 1.0f / s; return a * inv; }
 inline V3 vabs(V3 a) { return {fabsf(a.x), fabsf(a.y), fabsf(a.z)}; }
 inline V3 vmin(V3 a, V3 b) { return {fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)}; }
 inline V3 vmax(V3 a, V3 b) { return {fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; }
@@ -279,7 +281,7 @@ Hit intersect_cube(const Ray& ray, const GpuShape& f) {  // cube.wgsl:4-60
     hit.hit = true;
     hit.t = t;
     hit.position = madd(ray.origin, ray.direction, t);
-    V3 p = (hit.position - v3(f.position)) / half;
+    V3 p = vdivs(hit.position - v3(f.position), f.radius);
     V3 ap = vabs(p);
     if (ap.x > ap.y && ap.x > ap.z) hit.normal = v3(signf(p.x), 0, 0);
     else if (ap.y > ap.z) hit.normal = v3(0, signf(p.y), 0);
@@ -790,17 +792,18 @@ Hit march_fractal(Ctx& c, const Ray& ray, const GpuShape& f, F sdf_unit) {
     float disc = fmaf(b, b, -cs);
     if (disc < 0.0f) return hit;
     const float omega = 1.3f;
+    const float inv_radius = 1.0f / f.radius;  // p / radius = p * (1 / radius)
     float sq = sqrtf(disc);
     float t = fmax_(-b - sq, EPSILON);
     float max_t = -b + sq;
     float prev_d = 0.0f;
     for (u32 i = 0; i < c.cam->fractal_march_steps; i++) {
         V3 p = madd(ray.origin, ray.direction, t) - pos;
-        float d = sdf_unit(p / f.radius) * f.radius;
+        float d = sdf_unit(p * inv_radius) * f.radius;
         if (d < 0.0f && prev_d > 0.0f) {
             t -= prev_d * (omega - 1.0f);
             V3 p2 = madd(ray.origin, ray.direction, t) - pos;
-            float d2 = sdf_unit(p2 / f.radius) * f.radius;
+            float d2 = sdf_unit(p2 * inv_radius) * f.radius;
             t += d2;
             prev_d = d2;
             continue;
@@ -809,7 +812,7 @@ Hit march_fractal(Ctx& c, const Ray& ray, const GpuShape& f, F sdf_unit) {
             hit.hit = true;
             hit.t = t;
             hit.position = madd(ray.origin, ray.direction, t);
-            V3 local = (hit.position - pos) / f.radius;
+            V3 local = (hit.position - pos) * inv_radius;
             hit.normal = tet_normal(local, 0.5773f * EPSILON * 2.0f, sdf_unit);
             hit.uv = {0.0f, 0.0f};
             return hit;
@@ -1137,7 +1140,7 @@ V3 eval_brdf(Ctx& c, V3 wo, V3 wi, V3 n, const Mat& mat) {  // materials.wgsl:65
     V3 f = fresnel_schlick(v_dot_h, f0);
     float d = ggx_ndf(n_dot_h, alpha);
     float g = ggx_g1(n_dot_l, alpha) * ggx_g1(n_dot_v, alpha);
-    V3 specular = (f * (d * g)) / fmax_(4.0f * n_dot_l * n_dot_v, EPSILON);
+    V3 specular = vdivs(f * (d * g), fmax_(4.0f * n_dot_l * n_dot_v, EPSILON));
     V3 kd = (v3(1, 1, 1) - f) * (1.0f - mat.metallic);
     V3 diffuse = kd * mat.base_color * INV_PI;
     return diffuse + specular;
@@ -1271,7 +1274,7 @@ PathOut trace_path(Ctx& c, Ray ray) {
                 V3 light_point = v3(lf.position) + local_point;
                 V3 to_light = light_point - hit.position;
                 float light_dist = length(to_light);
-                V3 light_dir = to_light / light_dist;
+                V3 light_dir = vdivs(to_light, light_dist);
                 float n_dot_l = dot(n, light_dir);
                 if (n_dot_l > 0.0f) {
                     Ray shadow{madd(hit.position, n, EPSILON * 2.0f), light_dir};
@@ -1289,19 +1292,19 @@ PathOut trace_path(Ctx& c, Ray ray) {
                         float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
                         float w = a2 / fmax_(a2 + b2, 1e-10f);
                         if (light_solid_pdf > 0.0f)
-                            radiance = radiance + throughput * le * brdf * n_dot_l * w / pa;
+                            radiance = radiance + vdivs(throughput * le * brdf * n_dot_l * w, pa);
                     }
                 }
             }
         }
         BrdfSample bs = sample_brdf(c, wo, n, mat);
         if (length(bs.direction) < 0.001f || bs.pdf < EPSILON) break;
-        throughput = throughput * (bs.brdf_cos / bs.pdf);
+        throughput = throughput * vdivs(bs.brdf_cos, bs.pdf);
         ray = Ray{madd(hit.position, bs.direction, EPSILON * 2.0f), bs.direction};
         if (bounce >= 3u) {
             float survival = fmin_(fmax_(throughput.x, fmax_(throughput.y, throughput.z)), 0.95f);
             if (rand_f32(c) > survival) break;
-            throughput = throughput / survival;
+            throughput = vdivs(throughput, survival);
         }
         float lum = luminance(throughput);
         if (lum > c.cam->firefly_clamp) throughput = throughput * (c.cam->firefly_clamp / lum);
@@ -1414,7 +1417,7 @@ int pto_render(const PtoScene* sc, const GpuCamera* cam_in, u32 first_frame, u32
                 bsum += po.bounces;
                 float nn = fmax_((float)cam.sample_count, 1.0f);
                 V3 delta = po.radiance - mean;
-                V3 nm = mean + delta / nn;  // path_trace.wgsl:45-49
+                V3 nm = mean + vdivs(delta, nn);  // path_trace.wgsl:45-49
                 if (m2) {
                     V3 d2 = po.radiance - nm;
                     m2[idx * 3 + 0] = fmaf(delta.x, d2.x, m2[idx * 3 + 0]);

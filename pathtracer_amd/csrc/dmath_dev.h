@@ -155,8 +155,8 @@ PT_DEV float pow_(float x, float y) { return exp2_(y * log2_(x)); }
 }  // namespace dm
 
 // ---- vector helpers: fixed expression trees ------------------------------------------------------
-// dot = fma chain from the low index; cross = fma(a,b,-(c*d)); madd = fma(d,t,o); everything else is
-// unfused and left to right.
+// dot = fma chain from the low index; cross = fma(a,b,-(c*d)); madd = fma(d,t,o); vector / scalar is
+// vector * (1 / scalar); everything else is unfused and left to right.
 struct V2 { float x, y; };
 struct V3 { float x, y, z; };
 struct V4 { float x, y, z, w; };
@@ -178,6 +178,8 @@ PT_DEV V3 cross(V3 a, V3 b) {
 PT_DEV V3 madd(V3 o, V3 d, float t) { return v3(dm::fma_(d.x, t, o.x), dm::fma_(d.y, t, o.y), dm::fma_(d.z, t, o.z)); }
 PT_DEV float length(V3 a) { return dm::sqrt_(dot(a, a)); }
 PT_DEV V3 normalize(V3 a) { float inv = 1.0f / dm::sqrt_(dot(a, a)); return a * inv; }
+// vector / scalar = vector * (1 / scalar): one correctly rounded reciprocal, then three multiplies.
+PT_DEV V3 vdivs(V3 a, float s) { float inv = 1.0f / s; return a * inv; }
 PT_DEV V3 vabs(V3 a) { return v3(dm::abs_(a.x), dm::abs_(a.y), dm::abs_(a.z)); }
 PT_DEV V3 vmin(V3 a, V3 b) { return v3(dm::fmin_(a.x, b.x), dm::fmin_(a.y, b.y), dm::fmin_(a.z, b.z)); }
 PT_DEV V3 vmax(V3 a, V3 b) { return v3(dm::fmax_(a.x, b.x), dm::fmax_(a.y, b.y), dm::fmax_(a.z, b.z)); }

@@ -95,7 +95,7 @@ PT_DEV bool isect_cube(const Ray& ray, V3 inv_dir, const DPrim& g, float& t_out,
     t_out = t;
     if (FULL) {
         h->pos = madd(ray.o, ray.d, t);
-        V3 p = (h->pos - pos) / half;
+        V3 p = vdivs(h->pos - pos, r);
         V3 ap = vabs(p);
         if (ap.x > ap.y && ap.x > ap.z) h->normal = v3(signf(p.x), 0.0f, 0.0f);
         else if (ap.y > ap.z) h->normal = v3(0.0f, signf(p.y), 0.0f);
@@ -717,17 +717,18 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
     float disc = dm::fma_(b, b, -cs);
     if (disc < 0.0f) return false;
     const float omega = 1.3f;
+    const float inv_radius = 1.0f / radius;
     float sq = dm::sqrt_(disc);
     float t = dm::fmax_(-b - sq, PT_EPS);
     float max_t = -b + sq;
     float prev_d = 0.0f;
     for (uint32_t i = 0; i < march_steps; i++) {
         V3 p = madd(ray.o, ray.d, t) - pos;
-        float d = sdf_eval<true>(g, p / radius) * radius;
+        float d = sdf_eval<true>(g, p * inv_radius) * radius;
         if (d < 0.0f && prev_d > 0.0f) {
             t -= prev_d * (omega - 1.0f);
             V3 p2 = madd(ray.o, ray.d, t) - pos;
-            float d2 = sdf_eval<true>(g, p2 / radius) * radius;
+            float d2 = sdf_eval<true>(g, p2 * inv_radius) * radius;
             t += d2;
             prev_d = d2;
             continue;
@@ -742,7 +743,7 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
 PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) {
     V3 pos = v3p(g.p);
     h->pos = madd(ray.o, ray.d, t);
-    V3 local = (h->pos - pos) / g.p[3];
+    V3 local = (h->pos - pos) * (1.0f / g.p[3]);
     h->normal = tet_normal<true>(g, local, 0.5773f * PT_EPS * 2.0f);
     h->uv.x = 0.0f;
     h->uv.y = 0.0f;

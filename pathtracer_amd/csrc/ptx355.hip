@@ -151,7 +151,7 @@ PT_DEV void trace_body(const TraceParams& P) {
             V3 rad = v3(dm::fmax_(ps.radiance.x, 0.0f), dm::fmax_(ps.radiance.y, 0.0f), dm::fmax_(ps.radiance.z, 0.0f));
             float nn = dm::fmax_((float)(P.first_sample + k), 1.0f);
             V3 delta = rad - mean;
-            V3 nm = mean + delta / nn;
+            V3 nm = mean + vdivs(delta, nn);
             if (P.m2) {
                 V3 d2 = rad - nm;
                 px_f[3 * 64] = dm::fma_(delta.x, d2.x, px_f[3 * 64]);

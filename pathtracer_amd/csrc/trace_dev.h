@@ -324,7 +324,7 @@ PT_DEV V3 eval_brdf(V3 wo, V3 wi, V3 n, const MatD& mat) {  // materials.wgsl:65
     V3 f = f0 + (v3(1.0f, 1.0f, 1.0f) - f0) * w5;  // utils.wgsl:44-48
     float d = ggx_ndf(n_dot_h, alpha);
     float g = ggx_g1(n_dot_l, alpha) * ggx_g1(n_dot_v, alpha);
-    V3 specular = (f * (d * g)) / dm::fmax_(4.0f * n_dot_l * n_dot_v, PT_EPS);
+    V3 specular = vdivs(f * (d * g), dm::fmax_(4.0f * n_dot_l * n_dot_v, PT_EPS));
     V3 kd = (v3(1.0f, 1.0f, 1.0f) - f) * (1.0f - mat.metallic);
     V3 diffuse = kd * mat.base_color * PT_INV_PI;
     return diffuse + specular;
@@ -369,7 +369,7 @@ PT_DEV bool sample_brdf(uint32_t& rng, V3 wo, V3 n, const MatD& mat, V3& wi_out,
     // path_trace.wgsl:158: length(direction) < 0.001 || pdf < EPSILON
     if (length(wi) < 0.001f || pdf < PT_EPS) return false;
     wi_out = wi;
-    weight = (brdf * n_dot_l) / pdf;
+    weight = vdivs(brdf * n_dot_l, pdf);
     return true;
 }
 // materials.wgsl:163-195.  Returns false when the sampled direction is (near) zero (path_trace.wgsl:99-101).
@@ -529,7 +529,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
             V3 light_point = lpos + local_point;
             V3 to_light = light_point - hpos;
             float light_dist = length(to_light);
-            V3 light_dir = to_light / light_dist;
+            V3 light_dir = vdivs(to_light, light_dist);
             float n_dot_l = dot(n, light_dir);
             if (n_dot_l > 0.0f) {
                 // The unoccluded contribution is a pure function of values known here; it is evaluated
@@ -543,7 +543,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
                 float pa = light_solid_pdf * (float)num_lights;
                 float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
                 float w = a2 / dm::fmax_(a2 + b2, 1e-10f);
-                V3 contrib = ps.throughput * v3p(L.le) * brdf * n_dot_l * w / pa;
+                V3 contrib = vdivs(ps.throughput * v3p(L.le) * brdf * n_dot_l * w, pa);
                 const bool lit = light_solid_pdf > 0.0f;
                 Ray sray;
                 sray.o = madd(hpos, n, PT_EPS * 2.0f);
@@ -585,7 +585,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     if (ps.bounce >= 3u) {  // path_trace.wgsl:166-172
         float survival = dm::fmin_(dm::fmax_(ps.throughput.x, dm::fmax_(ps.throughput.y, ps.throughput.z)), 0.95f);
         if (rand_f32(ps.rng) > survival) return true;
-        ps.throughput = ps.throughput / survival;
+        ps.throughput = vdivs(ps.throughput, survival);
     }
     float lum = dot(ps.throughput, v3(0.2126f, 0.7152f, 0.0722f));
     if (lum > cam.firefly_clamp) ps.throughput = ps.throughput * (cam.firefly_clamp / lum);
