@@ -161,6 +161,11 @@ void* ptx_device_moments(ptx_ctx* ctx);
 int ptx_merge_moments(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, uint32_t n_a,
                       const void* other_mean4, const void* other_m2, uint32_t n_b, const ptx_camera* cam);
 
+/* Re-derives the rgba8 output of pixels [first_pixel, first_pixel + n_pixels) from the accumulation buffer
+ * (apply_tonemap + rgba8unorm store, tonemap.wgsl:27-42, path_trace.wgsl:52-53): for accumulation data
+ * that arrived from another GPU. */
+int ptx_tonemap(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, const ptx_camera* cam);
+
 int ptx_read_stats(ptx_ctx* ctx, ptx_stats* out);
 
 /* Name of the kernel variant ptx_trace* launches for the uploaded scene (scene records staged in LDS or

@@ -38,6 +38,7 @@ SYMBOLS = [
     ("ptx_device_accum", _P, [_P]),
     ("ptx_device_moments", _P, [_P]),
     ("ptx_merge_moments", C.c_int, [_P, _U, _U, _U, _P, _P, _U, _P]),
+    ("ptx_tonemap", C.c_int, [_P, _U, _U, _P]),
     ("ptx_read_stats", C.c_int, [_P, C.POINTER(PtxStats)]),
     ("ptx_trace_kernel_name", C.c_char_p, [_P]),
     ("ptx_kernel_time", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U)]),

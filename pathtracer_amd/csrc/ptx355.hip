@@ -229,6 +229,14 @@ extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* 
     out_rgba8[p] = tonemap_rgba8(cam, m);
 }
 
+// Re-derives the rgba8 image from the accumulation buffer (tonemap.wgsl + rgba8unorm store).
+extern "C" __global__ void ptx_tonemap_kernel(const float4* accum, uint32_t* out_rgba8, uint32_t first, uint32_t n_pixels, const ptx_camera cam) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = accum[(size_t)first + i];
+    out_rgba8[(size_t)first + i] = tonemap_rgba8(cam, v3(a.x, a.y, a.z));
+}
+
 extern "C" __global__ void ptx_kat_math_kernel(int op, uint32_t n, const float* a, const float* b, float* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -760,6 +768,18 @@ int ptx_merge_moments(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, uint3
     hipLaunchKernelGGL(ptx_merge_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, c->stream, c->accum,
                        (c->moments && other_m2) ? c->m2 : nullptr, c->out, first_pixel, n_pixels, (float)n_a,
                        (const float4*)other_mean4, (const float*)other_m2, (float)n_b, *cam);
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_tonemap(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, const ptx_camera* cam) {
+    if (!c || !cam) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_tonemap before ptx_resize");
+    if ((uint64_t)first_pixel + n_pixels > (uint64_t)c->w * c->h) return fail(c, PTX_ERR_BAD_ARG, "pixel range outside the frame");
+    if (n_pixels == 0) return PTX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, c->stream, c->accum, c->out, first_pixel,
+                       n_pixels, *cam);
     HIP_TRY(c, hipGetLastError());
     return PTX_OK;
 }

@@ -129,6 +129,10 @@ class PathTracer:
         self._ck(self.lib.ptx_merge_moments(self.h, first_pixel, n_pixels, n_a, C.c_void_p(other_mean4_ptr),
                                             C.c_void_p(other_m2_ptr) if other_m2_ptr else None, n_b, _p(cam)), "ptx_merge_moments")
 
+    def tonemap(self, first_pixel: int, n_pixels: int, cam):
+        cam = _arr(cam, CAMERA_DT)
+        self._ck(self.lib.ptx_tonemap(self.h, first_pixel, n_pixels, _p(cam)), "ptx_tonemap")
+
     def stats(self) -> dict:
         s = _lib.PtxStats()
         self._ck(self.lib.ptx_read_stats(self.h, C.byref(s)), "ptx_read_stats")

@@ -69,7 +69,7 @@ def device_tensor(ptr: int, shape, dtype, device):
     return torch.as_tensor(raw, device=device)
 
 
-def assemble_tiles(tracer, dist, device):
+def assemble_tiles(tracer, dist, device, cam=None):
     """Tile partition epilogue: SUM all-reduce of the disjoint accumulation and output buffers."""
     import torch
     tracer.sync()
@@ -77,6 +77,9 @@ def assemble_tiles(tracer, dist, device):
     acc = device_tensor(tracer.device_accum_ptr(), (n * 4,), torch.float32, device)
     dist.all_reduce(acc)
     torch.cuda.synchronize(device)
+    if cam is not None:
+        tracer.tonemap(0, n, cam)
+        tracer.sync()
 
 
 def merge_sample_split(tracer, dist, device, counts: List[int], cam):
@@ -91,15 +94,9 @@ def merge_sample_split(tracer, dist, device, counts: List[int], cam):
     m2 = device_tensor(m2p, (n, 3), torch.float32, device) if m2p else None
     slices = pixel_slices(n, world)
     # slice exchange: rank j receives slice j of every rank's partial
-    send_a = [acc[f:f + c].contiguous() for f, c in slices]
     mine = slices[rank]
-    recv_a = [torch.empty((mine[1], 4), dtype=torch.float32, device=device) for _ in range(world)]
-    dist.all_to_all(recv_a, send_a)
-    recv_m = None
-    if m2 is not None:
-        send_m = [m2[f:f + c].contiguous() for f, c in slices]
-        recv_m = [torch.empty((mine[1], 3), dtype=torch.float32, device=device) for _ in range(world)]
-        dist.all_to_all(recv_m, send_m)
+    recv_a = _exchange_slices(dist, acc, slices, rank, world, 4, device)
+    recv_m = _exchange_slices(dist, m2, slices, rank, world, 3, device) if m2 is not None else None
     # fixed rank order: start from partial 0, fold in 1, 2, ...
     acc[mine[0]:mine[0] + mine[1]].copy_(recv_a[0])
     if m2 is not None:
@@ -117,7 +114,24 @@ def merge_sample_split(tracer, dist, device, counts: List[int], cam):
     for (f, c), g in zip(slices, gathered):
         acc[f:f + c].copy_(g)
     torch.cuda.synchronize(device)
+    tracer.tonemap(0, n, cam)  # the other ranks' slices arrived as means only
+    tracer.sync()
     return n_a
+
+
+def _exchange_slices(dist, buf, slices, rank, world, width, device):
+    """Every rank sends slice j of `buf` to rank j and receives slice `rank` from everyone.  RCCL: one
+    all-to-all (all peer links busy at once); gloo (tests): one gather per destination."""
+    import torch
+    mine = slices[rank]
+    recv = [torch.empty((mine[1], width), dtype=torch.float32, device=device) for _ in range(world)]
+    send = [buf[f:f + c].contiguous() for f, c in slices]
+    if dist.get_backend() == "nccl":
+        dist.all_to_all(recv, send)
+    else:
+        for dst in range(world):
+            dist.gather(send[dst], recv if rank == dst else None, dst=dst)
+    return recv
 
 
 def _all_gather_uneven(dist, out_list, mine, slices, device):
