@@ -16,6 +16,33 @@
 
 #define PT_DEV static __device__ __forceinline__
 
+// Diagnostic builds (-DPTX_SITE_STATS): per code site, how often a wave ran it and with how many lanes.
+#ifdef PTX_SITE_STATS
+#define PT_NSITES 96
+__device__ unsigned long long pt_sites[PT_NSITES * 2];
+static __device__ __noinline__ void pt_site(int i) {
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+        atomicAdd(&pt_sites[2 * i], 1ull);
+        atomicAdd(&pt_sites[2 * i + 1], (unsigned long long)__popcll(m));
+    }
+}
+static __device__ __noinline__ void pt_site_typed(int base, uint32_t type) {
+    for (uint32_t T = 0; T < 18u; T++) {
+        unsigned long long m = __ballot((type > 16u ? 17u : type) == T);
+        if (m != 0ull && (int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+            atomicAdd(&pt_sites[2 * (base + T)], 1ull);
+            atomicAdd(&pt_sites[2 * (base + T) + 1], (unsigned long long)__popcll(m));
+        }
+    }
+}
+#define PT_SITE(i) pt_site(i)
+#define PT_SITE_TYPED(b, t) pt_site_typed(b, t)
+#else
+#define PT_SITE(i)
+#define PT_SITE_TYPED(b, t)
+#endif
+
 namespace dm {
 
 PT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }

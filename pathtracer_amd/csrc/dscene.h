@@ -84,3 +84,4 @@ struct DScene {
     uint32_t has_fractals;    // any Mandelbulb / Julia figure in the BVH: selects the kernel variant with their marchers
     uint32_t lds_scene_bytes; // > 0: the scene records fit in LDS and the LDS-staged kernel is used
 };
+

@@ -643,6 +643,7 @@ PT_DEV bool march_torus(const Ray& ray, const DPrim& g, float& t_out) {
     float max_t = dm::fmin_(-b + sq, PT_MAX_T);
     float prev_d = 0.0f;
     for (int i = 0; i < 128; i++) {
+        PT_SITE(40);
         V3 p = madd(ray.o, ray.d, t) - pos;
         float d = sdf_torus(p, major_r, minor_r);
         if (d < 0.0f && prev_d > 0.0f) {
@@ -687,6 +688,7 @@ PT_DEV bool march_mebius(const Ray& ray, const DPrim& g, float& t_out) {
     float t = dm::fmax_(-b - sq, PT_EPS);
     float max_t = -b + sq;
     for (int i = 0; i < 256; i++) {
+        PT_SITE(41);
         V3 p = madd(ray.o, ray.d, t) - pos;
         float d = sdf_mebius(p, R);
         if (dm::abs_(d) < PT_EPS * t * 0.5f) { t_out = t; return true; }
@@ -723,6 +725,7 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
     float max_t = -b + sq;
     float prev_d = 0.0f;
     for (uint32_t i = 0; i < march_steps; i++) {
+        PT_SITE(42);
         V3 p = madd(ray.o, ray.d, t) - pos;
         float d = sdf_eval<true>(g, p * inv_radius) * radius;
         if (d < 0.0f && prev_d > 0.0f) {
@@ -754,6 +757,7 @@ PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) 
 template <bool FRAC>
 PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t march_steps, float& t, uint32_t& sub) {
     sub = 0u;
+    PT_SITE_TYPED(10, g.type);
     switch (g.type) {
         case FIG_SPHERE: return isect_sphere<false>(ray, g, t, nullptr, false);
         case FIG_PLANE: return isect_plane<false>(ray, g, t, nullptr, false);

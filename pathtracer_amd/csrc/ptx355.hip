@@ -138,13 +138,14 @@ PT_DEV void trace_body(const TraceParams& P) {
             uint32_t fig;
             local_bounces += 1u;
             const bool first = ps.bounce == 0u;
-            done = bounce_step<FRAC>(sc, P.cam, ps, st, px_f + PT_PIXEL_FIELDS * 64u, fig, n_shadow);
+            done = bounce_step<FRAC, !LDS_SCENE>(sc, P.cam, ps, st, px_f + PT_PIXEL_FIELDS * 64u, fig, n_shadow);
             PT_TICK(3);
             if (first) px_u[8 * 64] = fig;
             if (!done && ps.bounce >= P.cam.max_bounces) done = true;
         }
         PT_TICK(4);
         if (done) {
+            PT_SITE(36);
             // path_trace.wgsl:181 and :44-49
             const uint32_t k = px_u[6 * 64];
             V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
@@ -261,9 +262,10 @@ extern "C" __global__ void ptx_kat_math_kernel(int op, uint32_t n, const float* 
     out[i] = r;
 }
 
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(const DScene sc, const ptx_camera cam, uint32_t n,
-                                                                            const float* rays, const float* max_t, uint32_t* hit_id,
-                                                                            float* hit_t, uint32_t* shadow) {
+// Unit hook: one ray per lane through the same traversal code as the render kernels (WALK as they pick it).
+template <bool WALK>
+PT_DEV void kat_trace_body(const DScene& sc, const ptx_camera& cam, uint32_t n, const float* rays, const float* max_t, uint32_t* hit_id,
+                           float* hit_t, uint32_t* shadow) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     StackEntry* st = lds_stack + (size_t)wave * sc.stack_entries * 64u + lane;
@@ -275,10 +277,20 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(con
     Ray r2 = ray;
     float t;
     uint32_t slot, sub;
-    trace_closest<true>(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot, sub);
+    trace_closest<true, WALK>(sc, r2, vrcp(ray.d), cam.fractal_march_steps, st, t, slot, sub);
     hit_id[i] = slot == PT_SLOT_NONE ? 0xFFFFFFFFu : slot_prim(sc, slot).fig;
     hit_t[i] = slot == PT_SLOT_NONE ? PT_MAX_T : t;
-    if (shadow && max_t) shadow[i] = trace_shadow<true>(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;
+    if (shadow && max_t) shadow[i] = trace_shadow<true, WALK>(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;
+}
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(const DScene sc, const ptx_camera cam, uint32_t n,
+                                                                            const float* rays, const float* max_t, uint32_t* hit_id,
+                                                                            float* hit_t, uint32_t* shadow) {
+    kat_trace_body<true>(sc, cam, n, rays, max_t, hit_id, hit_t, shadow);
+}
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel_loop(const DScene sc, const ptx_camera cam, uint32_t n,
+                                                                                 const float* rays, const float* max_t, uint32_t* hit_id,
+                                                                                 float* hit_t, uint32_t* shadow) {
+    kat_trace_body<false>(sc, cam, n, rays, max_t, hit_id, hit_t, shadow);
 }
 
 // ================================================================================================
@@ -784,6 +796,18 @@ int ptx_tonemap(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, const ptx_c
     return PTX_OK;
 }
 
+#ifdef PTX_SITE_STATS
+// Diagnostic builds only: reads and clears the per-site counters ({wave executions, lanes} per site).
+extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
+    if (n_pairs > PT_NSITES) n_pairs = PT_NSITES;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_sites), (size_t)n_pairs * 16) != hipSuccess) return -1;
+    static unsigned long long zeros[PT_NSITES * 2];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pt_sites), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 const char* ptx_trace_kernel_name(const ptx_ctx* c) {
     if (!c || !c->have_scene) return "";
     const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
@@ -856,8 +880,13 @@ int ptx_kat_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t n, const float* ra
         rc = fail(c, PTX_ERR_HIP, "ptx_kat_trace: copy in");
     } else {
         size_t lds = (size_t)PTX_WAVES_PER_BLOCK * c->sc.stack_entries * 64u * sizeof(StackEntry);
-        hipLaunchKernelGGL(ptx_kat_trace_kernel, dim3((n + PTX_BLOCK - 1u) / PTX_BLOCK), dim3(PTX_BLOCK), lds, c->stream, c->sc, *cam, n,
-                           dr, want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
+        // Same traversal variant as ptx_trace picks for this scene (the records themselves stay in global memory here).
+        if (c->sc.lds_scene_bytes > 0u)
+            hipLaunchKernelGGL(ptx_kat_trace_kernel_loop, dim3((n + PTX_BLOCK - 1u) / PTX_BLOCK), dim3(PTX_BLOCK), lds, c->stream, c->sc,
+                               *cam, n, dr, want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
+        else
+            hipLaunchKernelGGL(ptx_kat_trace_kernel, dim3((n + PTX_BLOCK - 1u) / PTX_BLOCK), dim3(PTX_BLOCK), lds, c->stream, c->sc, *cam, n,
+                               dr, want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(hit_id, did, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(hit_t, dt, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             (want_shadow && hipMemcpy(shadow, dsh, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess))

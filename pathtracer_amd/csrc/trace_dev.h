@@ -28,9 +28,18 @@ PT_DEV float intersect_aabb(V3 o, V3 inv_dir, const float* bmin, const float* bm
 // the current closest distance gives the same outcome.
 typedef uint2 StackEntry;
 
+// Two loop shapes run the same per-lane sequence of box and primitive tests (the reference's):
+//   WALK = false (*_loop): one loop whose iteration is "pop, then either test the two child boxes or test every
+//          primitive of the leaf".  Best for scenes of a few mixed-type primitives (the LDS-staged kernels).
+//   WALK = true (*_walk): each round first walks inner nodes until the lane stands at a leaf primitive, then all
+//          lanes test one primitive each ("while-while").  Best for meshes, where the tests are uniform
+//          code and the box walk is the divergent part (+11 % on the teapot scene).
+// Serving one primitive type at a time to all lanes waiting for it (cheapest first, or costly types only)
+// was measured slower on every scene: at most 3-5 lanes of a wave want a ray marcher at any time.
+
 // Closest hit over non-subtracted figures (bvh.wgsl:236-305): distance and primitive slot.
 template <bool FRAC>
-PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
+PT_DEV void trace_positive_loop(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
                            float& t_best, uint32_t& slot_best, uint32_t& sub_best) {
     t_best = PT_MAX_T;
     slot_best = PT_SLOT_NONE;
@@ -63,6 +72,7 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
                     }
                 }
             } else {
+                PT_SITE(2);
                 const DNodePair& nd = sc.pairs[ref];
                 float tl = intersect_aabb(ray.o, inv_dir, nd.lmin, nd.lmax);
                 float tr = intersect_aabb(ray.o, inv_dir, nd.rmin, nd.rmax);
@@ -87,6 +97,7 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
     }
     // bvh.wgsl:192-209: planes, tested linearly after the BVH.
     for (uint32_t i = 0; i < sc.ninf; i++) {
+        PT_SITE(30);
         const DPrim& g = sc.inf[i];
         float ht;
         uint32_t sub;
@@ -96,6 +107,91 @@ PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_
             sub_best = sub;
         }
     }
+}
+
+template <bool FRAC>
+PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
+                           float& t_best, uint32_t& slot_best, uint32_t& sub_best) {
+    t_best = PT_MAX_T;
+    slot_best = PT_SLOT_NONE;
+    sub_best = 0u;
+    if (sc.nprim > 0u) {
+        int sp = 0;
+        uint32_t cur = sc.root_ref;
+        float cur_t = intersect_aabb(ray.o, inv_dir, sc.root_min, sc.root_max);
+        bool have = true;
+        uint32_t pi = 0u, pend = 0u;  // WALK: primitives [pi, pend) of the current leaf are still to be tested
+        for (;;) {
+            bool finished = false;
+            while (pi >= pend) {
+                PT_SITE(1);
+                if (!have) {
+                    if (sp == 0) { finished = true; break; }
+                    sp -= 1;
+                    StackEntry e = st[sp * 64];
+                    cur = e.x;
+                    cur_t = __uint_as_float(e.y);
+                }
+                have = false;
+                if (cur_t >= t_best) continue;
+                uint32_t cnt = cur >> PT_REF_BITS, ref = cur & PT_REF_MASK;
+                if (cnt > 0u) {
+                    pi = ref;
+                    pend = ref + cnt;
+                } else {
+                    PT_SITE(2);
+                    const DNodePair& nd = sc.pairs[ref];
+                    float tl = intersect_aabb(ray.o, inv_dir, nd.lmin, nd.lmax);
+                    float tr = intersect_aabb(ray.o, inv_dir, nd.rmin, nd.rmax);
+                    uint32_t le = nd.lref | (nd.lcnt << PT_REF_BITS), re = nd.rref | (nd.rcnt << PT_REF_BITS);
+                    // Far child is pushed first, the near child second; the near child would be popped
+                    // straight away, so it stays in registers (same stack-pointer arithmetic, incl. the
+                    // reference's `stack_ptr < 31` guards).
+                    bool left_near = tl < tr;
+                    uint32_t far_e = left_near ? re : le, near_e = left_near ? le : re;
+                    float far_t = left_near ? tr : tl, near_t = left_near ? tl : tr;
+                    if (far_t < t_best && sp < 31) {
+                        st[sp * 64] = make_uint2(far_e, __float_as_uint(far_t));
+                        sp += 1;
+                    }
+                    if (near_t < t_best && sp < 31) {
+                        cur = near_e;
+                        cur_t = near_t;
+                        have = true;
+                    }
+                }
+            }
+            if (finished) break;
+            const DPrim& g = sc.prims[pi];
+            float ht;
+            uint32_t sub;
+            if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht < t_best && ht > PT_EPS) {
+                t_best = ht;
+                slot_best = pi;
+                sub_best = sub;
+            }
+            pi += 1u;
+        }
+    }
+    // bvh.wgsl:192-209: planes, tested linearly after the BVH.
+    for (uint32_t i = 0; i < sc.ninf; i++) {
+        PT_SITE(30);
+        const DPrim& g = sc.inf[i];
+        float ht;
+        uint32_t sub;
+        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_best) {
+            t_best = ht;
+            slot_best = PT_SLOT_INF | i;
+            sub_best = sub;
+        }
+    }
+}
+
+template <bool FRAC, bool WALK>
+PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
+                           float& t_best, uint32_t& slot_best, uint32_t& sub_best) {
+    if (WALK) trace_positive_walk<FRAC>(sc, ray, inv_dir, march_steps, st, t_best, slot_best, sub_best);
+    else trace_positive_loop<FRAC>(sc, ray, inv_dir, march_steps, st, t_best, slot_best, sub_best);
 }
 
 // ---- CSG subtraction (bvh.wgsl:18-188) ----------------------------------------------------------------
@@ -190,10 +286,10 @@ PT_DEV const DPrim& slot_prim(const DScene& sc, uint32_t slot) {
     return (slot & PT_SLOT_INF) ? sc.inf[slot & ~PT_SLOT_INF] : sc.prims[slot];
 }
 // bvh.wgsl:143-188.  `ray` is updated to the ray that produced the final hit (its local distance t).
-template <bool FRAC>
+template <bool FRAC, bool WALK>
 PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st, float& t, uint32_t& slot,
                           uint32_t& sub) {
-    trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
+    trace_positive<FRAC, WALK>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
     if (sc.nneg > 0u && slot != PT_SLOT_NONE) {
         for (uint32_t attempt = 0; attempt < 8u; attempt++) {
             V3 hp = madd(ray.o, ray.d, t);
@@ -204,15 +300,16 @@ PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march
             if (min_exit >= PT_MAX_T) break;
             float advance = min_exit + PT_EPS * 2.0f;
             ray.o = madd(ray.o, ray.d, advance);
-            trace_positive<FRAC>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
+            trace_positive<FRAC, WALK>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
             if (slot == PT_SLOT_NONE) break;
         }
     }
 }
 
 // Any-hit occlusion (bvh.wgsl:308-362).
+// Any-hit occlusion (bvh.wgsl:308-362).
 template <bool FRAC>
-PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
+PT_DEV bool trace_shadow_loop(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
     V3 inv_dir = vrcp(ray.d);
     const float t_lim = max_t - PT_EPS;
     if (sc.nprim > 0u) {
@@ -232,6 +329,7 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
                     }
                 } else {
                     // Left is pushed, then right (bvh.wgsl:346-353); right would be popped next.
+                    PT_SITE(2);
                     const DNodePair& nd = sc.pairs[ref];
                     float tl = intersect_aabb(ray.o, inv_dir, nd.lmin, nd.lmax);
                     float tr = intersect_aabb(ray.o, inv_dir, nd.rmin, nd.rmax);
@@ -254,6 +352,7 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
         }
     }
     for (uint32_t i = 0; i < sc.ninf; i++) {  // bvh.wgsl:212-232
+        PT_SITE(30);
         const DPrim& g = sc.inf[i];
         float ht;
         uint32_t sub;
@@ -261,6 +360,77 @@ PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t
             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
     }
     return false;
+}
+
+template <bool FRAC>
+PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
+    V3 inv_dir = vrcp(ray.d);
+    const float t_lim = max_t - PT_EPS;
+    bool occluded = false;
+    if (sc.nprim > 0u) {
+        int sp = 0;
+        uint32_t cur = sc.root_ref;
+        float cur_t = intersect_aabb(ray.o, inv_dir, sc.root_min, sc.root_max);
+        bool have = true;
+        uint32_t pi = 0u, pend = 0u;
+        for (;;) {
+            bool finished = false;
+            while (pi >= pend) {
+                PT_SITE(1);
+                if (!have) {
+                    if (sp == 0) { finished = true; break; }
+                    sp -= 1;
+                    StackEntry e = st[sp * 64];
+                    cur = e.x;
+                    cur_t = __uint_as_float(e.y);
+                }
+                have = false;
+                if (!(cur_t < max_t)) continue;
+                uint32_t cnt = cur >> PT_REF_BITS, ref = cur & PT_REF_MASK;
+                if (cnt > 0u) {
+                    pi = ref;
+                    pend = ref + cnt;
+                } else {
+                    // Left is pushed, then right (bvh.wgsl:346-353); right would be popped next.
+                    PT_SITE(2);
+                    const DNodePair& nd = sc.pairs[ref];
+                    float tl = intersect_aabb(ray.o, inv_dir, nd.lmin, nd.lmax);
+                    float tr = intersect_aabb(ray.o, inv_dir, nd.rmin, nd.rmax);
+                    if (sp < 31) {
+                        st[sp * 64] = make_uint2(nd.lref | (nd.lcnt << PT_REF_BITS), __float_as_uint(tl));
+                        sp += 1;
+                    }
+                    if (sp < 31) {
+                        cur = nd.rref | (nd.rcnt << PT_REF_BITS);
+                        cur_t = tr;
+                        have = true;
+                    }
+                }
+            }
+            if (finished) break;
+            const DPrim& g = sc.prims[pi];
+            float ht;
+            uint32_t sub;
+            if (g.type != FIG_SKIP && intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
+                if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) { occluded = true; break; }
+            pi += 1u;
+        }
+    }
+    if (occluded) return true;
+    for (uint32_t i = 0; i < sc.ninf; i++) {  // bvh.wgsl:212-232
+        PT_SITE(30);
+        const DPrim& g = sc.inf[i];
+        float ht;
+        uint32_t sub;
+        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
+            if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
+    }
+    return false;
+}
+
+template <bool FRAC, bool WALK>
+PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
+    return WALK ? trace_shadow_walk<FRAC>(sc, ray, max_t, march_steps, st) : trace_shadow_loop<FRAC>(sc, ray, max_t, march_steps, st);
 }
 
 // ---- textures.wgsl:13-29 ---------------------------------------------------------------------------
@@ -452,9 +622,10 @@ struct PathState {
 #endif
 };
 #define PT_PARK_FIELDS 23u  // per-lane LDS slots for values parked across the occlusion query
-template <bool FRAC>
+template <bool FRAC, bool WALK>
 PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, StackEntry* st, float* park, uint32_t& hit_fig,
                         uint32_t& n_shadow) {
+    PT_SITE(0);
     Ray ray = ps.ray;
     V3 inv_dir = vrcp(ray.d);
     float t;
@@ -464,7 +635,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     park[17 * 64] = ps.radiance.x; park[18 * 64] = ps.radiance.y; park[19 * 64] = ps.radiance.z;
     park[21 * 64] = __uint_as_float(ps.rng);
     park[22 * 64] = __uint_as_float(ps.bounce);
-    trace_closest<FRAC>(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot, sub);
+    trace_closest<FRAC, WALK>(sc, ray, inv_dir, cam.fractal_march_steps, st, t, slot, sub);
     ps.throughput = v3(park[14 * 64], park[15 * 64], park[16 * 64]);
     ps.radiance = v3(park[17 * 64], park[18 * 64], park[19 * 64]);
     ps.rng = __float_as_uint(park[21 * 64]);
@@ -475,6 +646,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
         ps.radiance = ps.radiance + ps.throughput * sample_skybox(sc, cam, ps.ray.d);
         return true;
     }
+    PT_SITE(32);
     const DPrim& g = slot_prim(sc, slot);
     hit_fig = g.fig;
     const DShade& sh = sc.shade[g.fig];
@@ -498,6 +670,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     V3 n = h.normal;
     if (dot(n, wo) < 0.0f) n = -n;
     if (mt.transmission > 0.5f) {  // path_trace.wgsl:97-105
+        PT_SITE(37);
         V3 dir;
         if (!sample_glass(ps.rng, wo, n, mt.ior, dir)) return true;
         ps.throughput = ps.throughput * base_color;
@@ -514,6 +687,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
     V3 hpos = h.pos;
     if (mt.roughness > 0.04f) {  // path_trace.wgsl:108-154
         const uint32_t num_lights = sc.nlight > 0u ? sc.nlight : 1u;  // empty list = one-element placeholder
+        PT_SITE(33);
         float pick = rand_f32(ps.rng);
         uint32_t light_pick = (uint32_t)(pick * (float)num_lights);
         uint32_t li = light_pick < num_lights - 1u ? light_pick : num_lights - 1u;
@@ -535,6 +709,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
                 // The unoccluded contribution is a pure function of values known here; it is evaluated
                 // before the occlusion query so that only it and the BSDF inputs (parked in LDS) stay
                 // live across the traversal.
+                PT_SITE(34);
                 V3 light_normal = normalize(light_point - lpos);
                 float cos_light = dm::abs_(dot(-light_dir, light_normal));
                 float light_solid_pdf = cos_light <= 0.0f ? 0.0f : L.area_pdf * (light_dist * light_dist) / cos_light;
@@ -560,7 +735,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
                 park[14 * 64] = ps.throughput.x; park[15 * 64] = ps.throughput.y; park[16 * 64] = ps.throughput.z;
                 park[17 * 64] = ps.radiance.x; park[18 * 64] = ps.radiance.y; park[19 * 64] = ps.radiance.z;
                 PT_TICK(1);
-                bool occluded = trace_shadow<FRAC>(sc, sray, light_dist, cam.fractal_march_steps, st);
+                bool occluded = trace_shadow<FRAC, WALK>(sc, sray, light_dist, cam.fractal_march_steps, st);
                 PT_TICK(2);
                 hpos = v3(park[0 * 64], park[1 * 64], park[2 * 64]);
                 n = v3(park[3 * 64], park[4 * 64], park[5 * 64]);
@@ -577,6 +752,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
             }
         }
     }
+    PT_SITE(35);
     V3 wi, weight;
     if (!sample_brdf(ps.rng, wo, n, mat, wi, weight)) return true;
     ps.throughput = ps.throughput * weight;
