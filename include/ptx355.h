@@ -179,10 +179,16 @@ int ptx_kernel_time(ptx_ctx* ctx, float* total_ms, uint32_t* launches);
 
 /* Unit hooks for known-answer tests, evaluated on the device.
  * ptx_kat_math: op 0 sin, 1 cos, 2 asin, 3 acos, 4 log, 5 log2, 6 exp2, 7 atan2(a,b), 8 pow(a,b),
- *   9 min(a,b), 10 max(a,b); host arrays of n floats.
+ *   9 min(a,b), 10 max(a,b), 11 sqrt, 12 a / b (the kernels' division: a * rcp(b)), 13 fma(a,b,a), 14 rcp(a);
+ *   host arrays of n floats.
+ * ptx_kat_exhaustive: runs the kernels' reciprocal (op 0) or square root (op 1) on all 2^32 binary32 inputs and
+ *   compares with the definition (correctly rounded, subnormals flushed for the reciprocal; IEEE for the
+ *   square root) evaluated on the device with the compiler's IEEE sequences; returns the number of inputs that
+ *   differ and one of them.
  * ptx_kat_trace: closest-hit figure index / t and (if max_t != NULL) shadow occlusion for n host rays
  *   (6 floats each: origin, direction) against the uploaded scene; cam supplies fractal_march_steps. */
 int ptx_kat_math(ptx_ctx* ctx, int op, uint32_t n, const float* a, const float* b, float* out);
+int ptx_kat_exhaustive(ptx_ctx* ctx, int op, uint64_t* n_bad, uint32_t* first_bad);
 int ptx_kat_trace(ptx_ctx* ctx, const ptx_camera* cam, uint32_t n, const float* rays, const float* max_t,
                   uint32_t* hit_id, float* hit_t, uint32_t* shadow);
 

@@ -42,6 +42,23 @@ static inline float fmax_(float a, float b) {
     return a > b ? a : b;
 }
 
+// Division.  WGSL specifies x / y to 2.5 ULP for |y| in [2^-126, 2^126] and lets implementations flush
+// subnormal values; the contract is
+//   rcp_(y)    = the correctly rounded 1/y, with a subnormal y treated as a zero of its sign (result: infinity)
+//                and a subnormal result replaced by a zero of its sign;
+//   div_(x, y) = x * rcp_(y)   (at most 1.5 ULP; a literal divisor C is written x * (1.0f / C), the same value).
+// On gfx950 rcp_ is the hardware estimate plus one fused Newton step (checked there against this definition
+// over all 2^32 inputs); sqrt stays the correctly rounded IEEE square root.
+static inline float rcp_(float y) {
+    if (y != y) return y + y;
+    uint32_t sign = f2u(y) & 0x80000000u;
+    if (std::fabs(y) < 1.17549435e-38f) return u2f(sign | 0x7f800000u);
+    float r = 1.0f / y;
+    if (std::fabs(r) < 1.17549435e-38f) return u2f(sign);
+    return r;
+}
+static inline float div_(float x, float y) { return x * rcp_(y); }
+
 static const float PIO2 = 1.57079632679489661923f;
 static const float PI_F = 3.14159265358979323846f;
 static const float PIO4 = 0.78539816339744830962f;
@@ -77,7 +94,7 @@ static inline float atan2_(float y, float x) {
     bool big = mn > 0.4142135623730950f * mx;
     float num = big ? mn - mx : mn;
     float den = big ? mn + mx : mx;
-    float t = num / den;
+    float t = div_(num, den);
     float z = t * t;
     float p = fmaf(z, fmaf(z, fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f), 1.99777106478e-1f), -3.33329491539e-1f);
     float r = fmaf(p * z, t, t);

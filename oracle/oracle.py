@@ -104,7 +104,7 @@ def render(scene: OracleScene, cam: np.ndarray, n: int, first_frame: int = 0, fi
 
 
 MATH_OPS = {"sin": 0, "cos": 1, "asin": 2, "acos": 3, "log": 4, "log2": 5, "exp2": 6, "atan2": 7, "pow": 8,
-            "min": 9, "max": 10, "sqrt": 11, "div": 12, "fma_aba": 13}
+            "min": 9, "max": 10, "sqrt": 11, "div": 12, "fma_aba": 13, "rcp": 14}
 
 
 def math_op(name: str, a, b=None) -> np.ndarray:

@@ -16,6 +16,8 @@
 //   length(v)     = sqrt(dot(v,v));  normalize(v) = v * (1/length(v));  vector / scalar = vector * (1/scalar)
 //   mix(a,b,t)    = a*(1-t) + b*t  (unfused);  every other vector expression is unfused, left to right
 //   min/max       = IEEE minNum/maxNum with -0 < +0
+//   x / y         = x * rcp(y), rcp = correctly rounded reciprocal that flushes subnormals (oracle/dmath.h);
+//                   sqrt = correctly rounded IEEE
 //   sin, cos, atan2, asin, acos, log, pow = oracle/dmath.h
 // Build with -O2 -ffp-contract=off and no fast-math so the compiler adds no fusing of its own.
 #include <algorithm>
@@ -109,8 +111,7 @@ inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline V3 operator*(float s, V3 a) { return {a.x * s, a.y * s, a.z * s}; }
-inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
-inline V3 operator/(V3 a, V3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline V3 operator/(V3 a, V3 b) { return {dm::div_(a.x, b.x), dm::div_(a.y, b.y), dm::div_(a.z, b.z)}; }
 inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
 inline float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 inline float dot2(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
@@ -120,9 +121,9 @@ inline V3 cross(V3 a, V3 b) {
 }
 inline V3 madd(V3 o, V3 d, float t) { return {fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)}; }
 inline float length(V3 a) { return sqrtf(dot(a, a)); }
-inline V3 normalize(V3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+inline V3 normalize(V3 a) { float inv = dm::rcp_(sqrtf(dot(a, a))); return a * inv; }
 // vector / scalar = vector * (1 / scalar): one correctly rounded reciprocal, then three multiplies.
-inline V3 vdivs(V3 a, float s) { float inv = 1.0f / s; return a * inv; }
+inline V3 vdivs(V3 a, float s) { float inv = dm::rcp_(s); return a * inv; }
 inline V3 vabs(V3 a) { return {fabsf(a.x), fabsf(a.y), fabsf(a.z)}; }
 inline V3 vmin(V3 a, V3 b) { return {fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)}; }
 inline V3 vmax(V3 a, V3 b) { return {fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; }
@@ -161,7 +162,7 @@ inline float rand_f32(Ctx& c) { c.rng = pcg_hash(c.rng); return (float)c.rng * 2
 struct Onb { V3 u, v, n; };
 inline Onb build_onb(V3 n) {  // utils.wgsl:6-13
     float s = n.z >= 0.0f ? 1.0f : -1.0f;
-    float a = -1.0f / (s + n.z);
+    float a = dm::div_(-1.0f, s + n.z);
     float b = n.x * n.y * a;
     Onb o;
     o.u = v3(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
@@ -198,7 +199,7 @@ inline V3 fresnel_schlick(float cos_theta, V3 f0) {  // utils.wgsl:44-48
     return f0 + (v3(1, 1, 1) - f0) * w;
 }
 inline float fresnel_schlick_scalar(float cos_theta, float ior) {  // utils.wgsl:51-57
-    float r0 = (1.0f - ior) / (1.0f + ior);
+    float r0 = dm::div_(1.0f - ior, 1.0f + ior);
     r0 = r0 * r0;
     float t = 1.0f - cos_theta;
     float t2 = t * t;
@@ -219,11 +220,11 @@ inline V3 sample_texture(const Ctx& c, i32 texture_id, V2 uv) {
     py = std::min(py, info.height - 1u);
     u32 idx = info.offset + py * info.width + px;
     u32 packed = idx < c.sc->npix ? c.sc->tex_pixels[idx] : 0u;
-    return v3((float)(packed & 0xFFu) / 255.0f, (float)((packed >> 8) & 0xFFu) / 255.0f,
-              (float)((packed >> 16) & 0xFFu) / 255.0f);
+    return v3((float)(packed & 0xFFu) * (1.0f / 255.0f), (float)((packed >> 8) & 0xFFu) * (1.0f / 255.0f),
+              (float)((packed >> 16) & 0xFFu) * (1.0f / 255.0f));
 }
 inline V2 sphere_uv(V3 d) {  // sphere.wgsl:34-37, skybox.wgsl:14-17, ellipsoid.wgsl:46-49
-    return {0.5f + dm::atan2_(d.z, d.x) / TWO_PI, 0.5f - dm::asin_(clampf(d.y, -1.0f, 1.0f)) / PI};
+    return {0.5f + dm::atan2_(d.z, d.x) * (1.0f / TWO_PI), 0.5f - dm::asin_(clampf(d.y, -1.0f, 1.0f)) * (1.0f / PI)};
 }
 
 // ---- figures ---------------------------------------------------------------------------------
@@ -252,7 +253,7 @@ Hit intersect_plane(const Ray& ray, const GpuShape& f) {  // plane.wgsl:4-30
     V3 n = v3(f.normal);
     float denom = dot(n, ray.direction);
     if (fabsf(denom) < EPSILON) return hit;
-    float t = dot(v3(f.position) - ray.origin, n) / denom;
+    float t = dm::div_(dot(v3(f.position) - ray.origin, n), denom);
     if (t < EPSILON) return hit;
     hit.hit = true;
     hit.t = t;
@@ -267,7 +268,7 @@ Hit intersect_cube(const Ray& ray, const GpuShape& f) {  // cube.wgsl:4-60
     Hit hit = miss_hit();
     V3 half = v3(f.radius, f.radius, f.radius);
     V3 box_min = v3(f.position) - half, box_max = v3(f.position) + half;
-    V3 inv_dir = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    V3 inv_dir = v3(dm::rcp_(ray.direction.x), dm::rcp_(ray.direction.y), dm::rcp_(ray.direction.z));
     V3 t1 = (box_min - ray.origin) * inv_dir, t2 = (box_max - ray.origin) * inv_dir;
     V3 tmin = vmin(t1, t2), tmax = vmax(t1, t2);
     float t_near = fmax_(fmax_(tmin.x, tmin.y), tmin.z);
@@ -304,7 +305,7 @@ Hit intersect_cylinder(const Ray& ray, const GpuShape& f) {  // cylinder.wgsl:4-
     float disc = fmaf(half_b, half_b, -(a * c));
     if (disc < 0.0f) return hit;
     float sqrtd = sqrtf(disc);
-    float inv_a = 1.0f / a;
+    float inv_a = dm::rcp_(a);
     for (int i = 0; i < 2; i++) {
         float t = i == 0 ? (-half_b - sqrtd) * inv_a : (-half_b + sqrtd) * inv_a;
         if (t < EPSILON) continue;
@@ -316,7 +317,7 @@ Hit intersect_cylinder(const Ray& ray, const GpuShape& f) {  // cylinder.wgsl:4-
             hit.position = p;
             hit.normal = normalize((p - pos) - axis * proj);
             float angle = dm::atan2_(hit.normal.z, hit.normal.x);
-            hit.uv = {angle / TWO_PI + 0.5f, (proj + half_h) / f.height};
+            hit.uv = {angle * (1.0f / TWO_PI) + 0.5f, dm::div_(proj + half_h, f.height)};
             return hit;
         }
     }
@@ -325,7 +326,7 @@ Hit intersect_cylinder(const Ray& ray, const GpuShape& f) {  // cylinder.wgsl:4-
         for (int sign_i = 0; sign_i < 2; sign_i++) {
             float cap_sign = sign_i == 1 ? -1.0f : 1.0f;
             V3 cap_center = pos + axis * half_h * cap_sign;
-            float t = dot(cap_center - ray.origin, axis * cap_sign) / (d_axis * cap_sign);
+            float t = dm::div_(dot(cap_center - ray.origin, axis * cap_sign), d_axis * cap_sign);
             if (t > EPSILON && t < hit.t) {
                 V3 p = madd(ray.origin, ray.direction, t);
                 V3 offset = p - cap_center;
@@ -334,7 +335,7 @@ Hit intersect_cylinder(const Ray& ray, const GpuShape& f) {  // cylinder.wgsl:4-
                     hit.t = t;
                     hit.position = p;
                     hit.normal = axis * cap_sign;
-                    hit.uv = {(offset.x / f.radius + 1.0f) * 0.5f, (offset.z / f.radius + 1.0f) * 0.5f};
+                    hit.uv = {(dm::div_(offset.x, f.radius) + 1.0f) * 0.5f, (dm::div_(offset.z, f.radius) + 1.0f) * 0.5f};
                 }
             }
         }
@@ -349,14 +350,14 @@ Hit intersect_cone(const Ray& ray, const GpuShape& f) {  // cone.wgsl:4-80 (line
     V3 oc = ray.origin - apex;
     float d_dot_v = dot(ray.direction, axis);
     float oc_dot_v = dot(oc, axis);
-    float cos2 = 1.0f / (1.0f + tan2);
+    float cos2 = dm::rcp_(1.0f + tan2);
     float a_c = fmaf(d_dot_v, d_dot_v, -(cos2 * dot(ray.direction, ray.direction)));
     float b_c = fmaf(d_dot_v, oc_dot_v, -(cos2 * dot(ray.direction, oc)));
     float c_c = fmaf(oc_dot_v, oc_dot_v, -(cos2 * dot(oc, oc)));
     float disc = fmaf(b_c, b_c, -(a_c * c_c));
     if (disc < 0.0f) return hit;
     float sqrtd = sqrtf(disc);
-    float inv_a = 1.0f / a_c;
+    float inv_a = dm::rcp_(a_c);
     for (int i = 0; i < 2; i++) {
         float t = i == 0 ? (-b_c - sqrtd) * inv_a : (-b_c + sqrtd) * inv_a;
         if (t < EPSILON) continue;
@@ -370,13 +371,13 @@ Hit intersect_cone(const Ray& ray, const GpuShape& f) {  // cone.wgsl:4-80 (line
             float n_proj = dot(to_p, axis);
             hit.normal = normalize(to_p - axis * n_proj * (1.0f + tan2));
             float angle = dm::atan2_(hit.normal.z, hit.normal.x);
-            hit.uv = {angle / TWO_PI + 0.5f, -proj / f.height};
+            hit.uv = {angle * (1.0f / TWO_PI) + 0.5f, dm::div_(-proj, f.height)};
             return hit;
         }
     }
     float d_axis2 = dot(ray.direction, axis);
     if (fabsf(d_axis2) > EPSILON) {
-        float t = dot(pos - ray.origin, axis) / d_axis2;
+        float t = dm::div_(dot(pos - ray.origin, axis), d_axis2);
         if (t > EPSILON && t < hit.t) {
             V3 p = madd(ray.origin, ray.direction, t);
             V3 offset = p - pos;
@@ -385,7 +386,7 @@ Hit intersect_cone(const Ray& ray, const GpuShape& f) {  // cone.wgsl:4-80 (line
                 hit.t = t;
                 hit.position = p;
                 hit.normal = -axis;
-                hit.uv = {(offset.x / f.radius + 1.0f) * 0.5f, (offset.z / f.radius + 1.0f) * 0.5f};
+                hit.uv = {(dm::div_(offset.x, f.radius) + 1.0f) * 0.5f, (dm::div_(offset.z, f.radius) + 1.0f) * 0.5f};
             }
         }
     }
@@ -396,7 +397,7 @@ Hit intersect_disc(const Ray& ray, const GpuShape& f) {  // disc.wgsl:4-35
     V3 n = v3(f.normal), pos = v3(f.position);
     float denom = dot(n, ray.direction);
     if (fabsf(denom) < EPSILON) return hit;
-    float t = dot(pos - ray.origin, n) / denom;
+    float t = dm::div_(dot(pos - ray.origin, n), denom);
     if (t < EPSILON) return hit;
     V3 p = madd(ray.origin, ray.direction, t);
     V3 offset = p - pos;
@@ -407,7 +408,7 @@ Hit intersect_disc(const Ray& ray, const GpuShape& f) {  // disc.wgsl:4-35
     hit.t = t;
     hit.position = p;
     hit.normal = denom < 0.0f ? n : -n;
-    hit.uv = {(offset.x / f.radius + 1.0f) * 0.5f, (offset.z / f.radius + 1.0f) * 0.5f};
+    hit.uv = {(dm::div_(offset.x, f.radius) + 1.0f) * 0.5f, (dm::div_(offset.z, f.radius) + 1.0f) * 0.5f};
     return hit;
 }
 // WGSL unpack2x16float: exact binary16 -> binary32.
@@ -430,7 +431,7 @@ inline bool mt_core(const Ray& ray, V3 v0, V3 e1, V3 e2, float* t_out, float* u_
     V3 h = cross(ray.direction, e2);
     float a = dot(e1, h);
     if (fabsf(a) < EPSILON) return false;
-    float fi = 1.0f / a;
+    float fi = dm::rcp_(a);
     V3 s = ray.origin - v0;
     float u = fi * dot(s, h);
     if (u < 0.0f || u > 1.0f) return false;
@@ -504,7 +505,7 @@ Hit intersect_tetrahedron(const Ray& ray, const GpuShape& f) {  // tetrahedron.w
 Hit intersect_ellipsoid(const Ray& ray, const GpuShape& f) {  // ellipsoid.wgsl:5-52
     Hit hit = miss_hit();
     V3 radii = v3(f.radius, fmax_(f.height, f.radius), fmax_(f.radius2, f.radius));
-    V3 inv_radii = v3(1.0f / radii.x, 1.0f / radii.y, 1.0f / radii.z);
+    V3 inv_radii = v3(dm::rcp_(radii.x), dm::rcp_(radii.y), dm::rcp_(radii.z));
     V3 pos = v3(f.position);
     V3 oc = (ray.origin - pos) * inv_radii;
     V3 dir = ray.direction * inv_radii;
@@ -514,7 +515,7 @@ Hit intersect_ellipsoid(const Ray& ray, const GpuShape& f) {  // ellipsoid.wgsl:
     float disc = fmaf(half_b, half_b, -(a * c));
     if (disc < 0.0f) return hit;
     float sqrtd = sqrtf(disc);
-    float inv_a = 1.0f / a;
+    float inv_a = dm::rcp_(a);
     float t = (-half_b - sqrtd) * inv_a;
     if (t < EPSILON) {
         t = (-half_b + sqrtd) * inv_a;
@@ -539,7 +540,7 @@ Hit intersect_paraboloid(const Ray& ray, const GpuShape& f) {  // paraboloid.wgs
     float disc = fmaf(b, b, -(4.0f * a * c));
     if (disc < 0.0f) return hit;
     float sqrtd = sqrtf(disc);
-    float inv_2a = 0.5f / a;
+    float inv_2a = dm::div_(0.5f, a);
     for (int i = 0; i < 2; i++) {
         float t = i == 0 ? (-b - sqrtd) * inv_2a : (-b + sqrtd) * inv_2a;
         if (t < EPSILON) continue;
@@ -552,14 +553,14 @@ Hit intersect_paraboloid(const Ray& ray, const GpuShape& f) {  // paraboloid.wgs
             V3 local = p - pos;
             hit.normal = normalize(v3(2.0f * local.x, -r, 2.0f * local.z));
             float angle = dm::atan2_(local.z, local.x);
-            hit.uv = {angle / TWO_PI + 0.5f, local_y / h};
+            hit.uv = {angle * (1.0f / TWO_PI) + 0.5f, dm::div_(local_y, h)};
             return hit;
         }
     }
     float d_y = d.y;
     if (fabsf(d_y) > EPSILON) {
         float cap_y = pos.y + h;
-        float t = (cap_y - ray.origin.y) / d_y;
+        float t = dm::div_(cap_y - ray.origin.y, d_y);
         if (t > EPSILON) {
             V3 p = madd(ray.origin, d, t);
             V3 local = p - pos;
@@ -570,7 +571,7 @@ Hit intersect_paraboloid(const Ray& ray, const GpuShape& f) {  // paraboloid.wgs
                 hit.position = p;
                 hit.normal = v3(0, 1, 0);
                 float s = sqrtf(r * h);
-                hit.uv = {local.x / s * 0.5f + 0.5f, local.z / s * 0.5f + 0.5f};
+                hit.uv = {dm::div_(local.x, s) * 0.5f + 0.5f, dm::div_(local.z, s) * 0.5f + 0.5f};
             }
         }
     }
@@ -582,14 +583,14 @@ Hit intersect_hyperboloid(const Ray& ray, const GpuShape& f) {  // hyperboloid.w
     V3 oc = ray.origin - pos, d = ray.direction;
     float r = f.radius;
     float half_h = f.height * 0.5f;
-    float inv_r2 = 1.0f / (r * r);
+    float inv_r2 = dm::rcp_(r * r);
     float a = (dot2(d.x, d.z, d.x, d.z) - d.y * d.y) * inv_r2;
     float b = 2.0f * (dot2(oc.x, oc.z, d.x, d.z) - oc.y * d.y) * inv_r2;
     float c = (dot2(oc.x, oc.z, oc.x, oc.z) - oc.y * oc.y) * inv_r2 - 1.0f;
     float disc = fmaf(b, b, -(4.0f * a * c));
     if (disc >= 0.0f) {
         float sqrtd = sqrtf(disc);
-        float inv_2a = 0.5f / a;
+        float inv_2a = dm::div_(0.5f, a);
         for (int i = 0; i < 2; i++) {
             float t = i == 0 ? (-b - sqrtd) * inv_2a : (-b + sqrtd) * inv_2a;
             if (t < EPSILON || t >= hit.t) continue;
@@ -602,7 +603,7 @@ Hit intersect_hyperboloid(const Ray& ray, const GpuShape& f) {  // hyperboloid.w
                 V3 local = p - pos;
                 hit.normal = normalize(v3(2.0f * local.x, -2.0f * local.y, 2.0f * local.z) * inv_r2);
                 float angle = dm::atan2_(local.z, local.x);
-                hit.uv = {angle / TWO_PI + 0.5f, (local_y + half_h) / f.height};
+                hit.uv = {angle * (1.0f / TWO_PI) + 0.5f, dm::div_(local_y + half_h, f.height)};
             }
         }
     }
@@ -610,7 +611,7 @@ Hit intersect_hyperboloid(const Ray& ray, const GpuShape& f) {  // hyperboloid.w
         float cap_y = pos.y + (cap == 1 ? half_h : -half_h);
         V3 cap_normal = cap == 1 ? v3(0, 1, 0) : v3(0, -1, 0);
         if (fabsf(d.y) > EPSILON) {
-            float t = (cap_y - ray.origin.y) / d.y;
+            float t = dm::div_(cap_y - ray.origin.y, d.y);
             if (t > EPSILON && t < hit.t) {
                 V3 p = madd(ray.origin, d, t);
                 V3 local = p - pos;
@@ -622,7 +623,7 @@ Hit intersect_hyperboloid(const Ray& ray, const GpuShape& f) {  // hyperboloid.w
                     hit.position = p;
                     hit.normal = cap_normal;
                     float s = sqrtf(cap_r2);
-                    hit.uv = {local.x / s * 0.5f + 0.5f, local.z / s * 0.5f + 0.5f};
+                    hit.uv = {dm::div_(local.x, s) * 0.5f + 0.5f, dm::div_(local.z, s) * 0.5f + 0.5f};
                 }
             }
         }
@@ -679,7 +680,7 @@ Hit intersect_torus(Ctx& c, const Ray& ray, const GpuShape& f) {  // torus.wgsl:
             float angle_major = dm::atan2_(local.z, local.x);
             float px = sqrtf(dot2(local.x, local.z, local.x, local.z)) - major_r;
             float angle_minor = dm::atan2_(local.y, px);
-            hit.uv = {angle_major / TWO_PI + 0.5f, angle_minor / TWO_PI + 0.5f};
+            hit.uv = {angle_major * (1.0f / TWO_PI) + 0.5f, angle_minor * (1.0f / TWO_PI) + 0.5f};
             return hit;
         }
         t += d * omega;
@@ -730,7 +731,7 @@ Hit intersect_mebius(Ctx& c, const Ray& ray, const GpuShape& f) {  // mebius.wgs
             V3 local = hit.position - pos;
             hit.normal = tet_normal(local, 0.5773f * EPSILON * 2.0f, sdf);
             float angle = dm::atan2_(local.z, local.x);
-            hit.uv = {angle / TWO_PI + 0.5f, 0.5f};
+            hit.uv = {angle * (1.0f / TWO_PI) + 0.5f, 0.5f};
             return hit;
         }
         t += d;
@@ -746,7 +747,7 @@ inline float sdf_mandelbulb(Ctx& c, V3 p, float power, int max_iter) {  // mande
         if (c.cnt) c.cnt->fractal_inner++;
         dz = fmaf(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
         float r = sqrtf(m);
-        float b = power * dm::acos_(clampf(w.y / r, -1.0f, 1.0f));
+        float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
         float a = power * dm::atan2_(w.x, w.z);
         float rp = dm::pow_(r, power);
         float sb, cb, sa, ca;
@@ -757,7 +758,7 @@ inline float sdf_mandelbulb(Ctx& c, V3 p, float power, int max_iter) {  // mande
         if (m > 256.0f) break;
     }
     float r = sqrtf(m);
-    return 0.25f * dm::log_(m) * r / dz;
+    return dm::div_(0.25f * dm::log_(m) * r, dz);
 }
 inline V4 quat_mult(V4 a, V4 b) {  // julia.wgsl:4-11 (sums left to right, unfused)
     return {a.x * b.x - a.y * b.y - a.z * b.z - a.w * b.w, a.x * b.y + a.y * b.x + a.z * b.w - a.w * b.z,
@@ -778,7 +779,7 @@ inline float sdf_julia(Ctx& c, V3 p, V4 cc, int max_iter) {  // julia.wgsl:13-32
     }
     float r = sqrtf(r2);
     float dr = sqrtf(dot4(dz, dz));
-    return 0.5f * r * dm::log_(r) / dr;
+    return dm::div_(0.5f * r * dm::log_(r), dr);
 }
 // mandelbulb.wgsl:32-101 and julia.wgsl:34-101 share the marcher.
 template <class F>
@@ -792,7 +793,7 @@ Hit march_fractal(Ctx& c, const Ray& ray, const GpuShape& f, F sdf_unit) {
     float disc = fmaf(b, b, -cs);
     if (disc < 0.0f) return hit;
     const float omega = 1.3f;
-    const float inv_radius = 1.0f / f.radius;  // p / radius = p * (1 / radius)
+    const float inv_radius = dm::rcp_(f.radius);  // p / radius = p * (1 / radius)
     float sq = sqrtf(disc);
     float t = fmax_(-b - sq, EPSILON);
     float max_t = -b + sq;
@@ -908,7 +909,7 @@ bool is_inside_figure(const Ctx& c, V3 p, u32 idx) {  // bvh.wgsl:18-64
             V3 oc = p - apex;
             float proj = dot(oc, n);
             if (proj > 0.0f || proj < -f.height) return false;
-            float cos2 = 1.0f / (1.0f + f.radius2);
+            float cos2 = dm::rcp_(1.0f + f.radius2);
             float r2 = dot(oc, oc);
             return proj * proj > cos2 * r2;
         }
@@ -934,7 +935,7 @@ float find_exit_t(const Ctx& c, const Ray& ray, u32 idx) {  // bvh.wgsl:67-129
         }
         case 2: {
             V3 half = v3(f.radius, f.radius, f.radius);
-            V3 inv_dir = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+            V3 inv_dir = v3(dm::rcp_(ray.direction.x), dm::rcp_(ray.direction.y), dm::rcp_(ray.direction.z));
             V3 t1 = ((pos - half) - ray.origin) * inv_dir, t2 = ((pos + half) - ray.origin) * inv_dir;
             V3 tmax = vmax(t1, t2);
             return fmin_(fmin_(tmax.x, tmax.y), tmax.z);
@@ -949,11 +950,11 @@ float find_exit_t(const Ctx& c, const Ray& ray, u32 idx) {  // bvh.wgsl:67-129
             float cc = dot(oc_perp, oc_perp) - f.radius * f.radius;
             float disc = fmaf(half_b, half_b, -(a * cc));
             if (disc < 0.0f) return MAX_T;
-            float t_far = (-half_b + sqrtf(disc)) / a;
+            float t_far = dm::div_(-half_b + sqrtf(disc), a);
             float d_axis = dot(ray.direction, axis);
             if (fabsf(d_axis) > EPSILON) {
-                float t_top = (half_h - dot(oc, axis)) / d_axis;
-                float t_bot = (-half_h - dot(oc, axis)) / d_axis;
+                float t_top = dm::div_(half_h - dot(oc, axis), d_axis);
+                float t_bot = dm::div_(-half_h - dot(oc, axis), d_axis);
                 return fmin_(t_far, fmax_(t_top, t_bot));
             }
             return t_far;
@@ -961,7 +962,7 @@ float find_exit_t(const Ctx& c, const Ray& ray, u32 idx) {  // bvh.wgsl:67-129
         case 4: {
             V3 apex = pos + axis * f.height;
             V3 oc = ray.origin - apex;
-            float cos2 = 1.0f / (1.0f + f.radius2);
+            float cos2 = dm::rcp_(1.0f + f.radius2);
             float d_dot_v = dot(ray.direction, axis);
             float oc_dot_v = dot(oc, axis);
             float a_c = fmaf(d_dot_v, d_dot_v, -(cos2 * dot(ray.direction, ray.direction)));
@@ -969,7 +970,7 @@ float find_exit_t(const Ctx& c, const Ray& ray, u32 idx) {  // bvh.wgsl:67-129
             float c_c = fmaf(oc_dot_v, oc_dot_v, -(cos2 * dot(oc, oc)));
             float disc = fmaf(b_c, b_c, -(a_c * c_c));
             if (disc < 0.0f) return MAX_T;
-            return (-b_c + sqrtf(disc)) / a_c;
+            return dm::div_(-b_c + sqrtf(disc), a_c);
         }
         default: return MAX_T;
     }
@@ -1005,7 +1006,7 @@ Hit trace_bvh_positive(Ctx& c, const Ray& ray) {  // bvh.wgsl:236-305
     Hit closest;
     closest.t = MAX_T;
     closest.hit = false;
-    V3 inv_dir = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    V3 inv_dir = v3(dm::rcp_(ray.direction.x), dm::rcp_(ray.direction.y), dm::rcp_(ray.direction.z));
     const GpuBvhNode* nodes = c.sc->nodes;
     // An empty BVH is uploaded by the reference as one zeroed node (bvh.rs:38-43); it can never
     // produce a hit, so it is skipped here.
@@ -1068,7 +1069,7 @@ Hit trace_bvh(Ctx& c, const Ray& ray) {  // bvh.wgsl:143-188
 }
 bool trace_shadow(Ctx& c, const Ray& ray, float max_t) {  // bvh.wgsl:308-362
     if (c.cnt) c.cnt->shadow_rays++;
-    V3 inv_dir = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    V3 inv_dir = v3(dm::rcp_(ray.direction.x), dm::rcp_(ray.direction.y), dm::rcp_(ray.direction.z));
     const GpuBvhNode* nodes = c.sc->nodes;
     if (c.sc->nprim > 0 && c.sc->nnode > 0) {
         u32 stack[32];
@@ -1116,15 +1117,15 @@ struct Mat { V3 base_color; float metallic; V3 emission; float roughness, emissi
 inline float ggx_ndf(float n_dot_h, float alpha) {  // materials.wgsl:17-21
     float a2 = alpha * alpha;
     float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
-    return a2 / (PI * denom * denom);
+    return dm::div_(a2, PI * denom * denom);
 }
 inline float ggx_g1(float n_dot_v, float alpha) {  // materials.wgsl:24-28
     float a2 = alpha * alpha;
     float denom = n_dot_v + sqrtf(a2 + (1.0f - a2) * n_dot_v * n_dot_v);
-    return 2.0f * n_dot_v / denom;
+    return dm::div_(2.0f * n_dot_v, denom);
 }
 inline float ggx_pdf(float n_dot_h, float v_dot_h, float alpha) {  // materials.wgsl:52-55
-    return ggx_ndf(n_dot_h, alpha) * n_dot_h / (4.0f * v_dot_h);
+    return dm::div_(ggx_ndf(n_dot_h, alpha) * n_dot_h, 4.0f * v_dot_h);
 }
 V3 eval_brdf(Ctx& c, V3 wo, V3 wi, V3 n, const Mat& mat) {  // materials.wgsl:65-90
     if (c.cnt) c.cnt->eval_brdf++;
@@ -1149,7 +1150,7 @@ struct BrdfSample { V3 direction{0, 0, 0}; V3 brdf_cos{0, 0, 0}; float pdf = 0.0
 inline V3 sample_ggx_half(Ctx& c, V3 n, float alpha) {  // materials.wgsl:38-49
     float rx = rand_f32(c), ry = rand_f32(c);
     float a2 = alpha * alpha;
-    float cos_theta = sqrtf((1.0f - ry) / (1.0f + (a2 - 1.0f) * ry));
+    float cos_theta = sqrtf(dm::div_(1.0f - ry, 1.0f + (a2 - 1.0f) * ry));
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
     float phi = TWO_PI * rx;
     float sp, cp;
@@ -1192,7 +1193,7 @@ BrdfSample sample_glass(Ctx& c, V3 wo, V3 n, const Mat& mat) {  // materials.wgs
     BrdfSample res;
     bool entering = dot(wo, n) > 0.0f;
     V3 face_n = entering ? n : -n;
-    float eta = entering ? 1.0f / mat.ior : mat.ior / 1.0f;
+    float eta = entering ? dm::rcp_(mat.ior) : mat.ior;  // ior / 1.0
     float cos_i = fabsf(dot(wo, face_n));
     float fresnel = fresnel_schlick_scalar(cos_i, mat.ior);
     res.brdf_cos = mat.base_color;
@@ -1284,13 +1285,13 @@ PathOut trace_path(Ctx& c, Ray ray) {
                         V3 light_normal = normalize(light_point - v3(lf.position));
                         float cos_light = fabsf(dot(-light_dir, light_normal));
                         float area = 4.0f * PI * lf.radius * lf.radius;  // lighting.wgsl:23-26
-                        float light_area_pdf = 1.0f / area;
-                        float light_solid_pdf = cos_light <= 0.0f ? 0.0f : light_area_pdf * (light_dist * light_dist) / cos_light;
+                        float light_area_pdf = dm::rcp_(area);
+                        float light_solid_pdf = cos_light <= 0.0f ? 0.0f : dm::div_(light_area_pdf * (light_dist * light_dist), cos_light);
                         V3 brdf = eval_brdf(c, wo, light_dir, n, mat);
                         float brdf_pdf_val = n_dot_l * INV_PI;
                         float pa = light_solid_pdf * (float)num_lights;
                         float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
-                        float w = a2 / fmax_(a2 + b2, 1e-10f);
+                        float w = dm::div_(a2, fmax_(a2 + b2, 1e-10f));
                         if (light_solid_pdf > 0.0f)
                             radiance = radiance + vdivs(throughput * le * brdf * n_dot_l * w, pa);
                     }
@@ -1307,7 +1308,7 @@ PathOut trace_path(Ctx& c, Ray ray) {
             throughput = vdivs(throughput, survival);
         }
         float lum = luminance(throughput);
-        if (lum > c.cam->firefly_clamp) throughput = throughput * (c.cam->firefly_clamp / lum);
+        if (lum > c.cam->firefly_clamp) throughput = throughput * (dm::div_(c.cam->firefly_clamp, lum));
     }
     out.radiance = v3(fmax_(radiance.x, 0.0f), fmax_(radiance.y, 0.0f), fmax_(radiance.z, 0.0f));
     return out;
@@ -1318,26 +1319,26 @@ Ray generate_ray(Ctx& c, float px_, float py_) {
     const GpuCamera& cam = *c.cam;
     float jx = rand_f32(c) - 0.5f, jy = rand_f32(c) - 0.5f;
     float px = px_ + jx, py = py_ + jy;
-    float ndc_x = (2.0f * px / (float)cam.width - 1.0f) * cam.aspect;
-    float ndc_y = 1.0f - 2.0f * py / (float)cam.height;
+    float ndc_x = (dm::div_(2.0f * px, (float)cam.width) - 1.0f) * cam.aspect;
+    float ndc_y = 1.0f - dm::div_(2.0f * py, (float)cam.height);
     V3 dir = normalize(v3(cam.right) * ndc_x + v3(cam.up) * ndc_y + v3(cam.forward) * cam.focal_length);
     return Ray{v3(cam.position), dir};
 }
 
 // ---- tonemap.wgsl -------------------------------------------------------------------------------
 inline float aces(float x) {  // tonemap.wgsl:4-11
-    return clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
+    return clampf(dm::div_(x * (2.51f * x + 0.03f), x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
 }
 inline float linear_to_srgb(float c) {  // tonemap.wgsl:19-23
     float lo = c * 12.92f;
-    float hi = 1.055f * dm::pow_(c, 1.0f / 2.4f) - 0.055f;
+    float hi = 1.055f * dm::pow_(c, (1.0f / 2.4f)) - 0.055f;
     return c <= 0.0031308f ? lo : hi;
 }
 inline V3 apply_tonemap(const GpuCamera& cam, V3 color) {  // tonemap.wgsl:27-42
     V3 e = color * cam.exposure;
     V3 m;
     switch (cam.tone_mapper) {
-        case 1u: m = v3(e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z)); break;
+        case 1u: m = v3(dm::div_(e.x, 1.0f + e.x), dm::div_(e.y, 1.0f + e.y), dm::div_(e.z, 1.0f + e.z)); break;
         case 2u: m = v3(clampf(e.x, 0, 1), clampf(e.y, 0, 1), clampf(e.z, 0, 1)); break;
         default: m = v3(aces(e.x), aces(e.y), aces(e.z)); break;
     }
@@ -1479,8 +1480,9 @@ void pto_math(int op, u32 n, const float* a, const float* b, float* out) {
             case 9: out[i] = dm::fmin_(a[i], b[i]); break;
             case 10: out[i] = dm::fmax_(a[i], b[i]); break;
             case 11: out[i] = sqrtf(a[i]); break;
-            case 12: out[i] = a[i] / b[i]; break;
+            case 12: out[i] = dm::div_(a[i], b[i]); break;
             case 13: out[i] = fmaf(a[i], b[i], a[i]); break;
+            case 14: out[i] = dm::rcp_(a[i]); break;
             default: out[i] = 0.0f;
         }
     }

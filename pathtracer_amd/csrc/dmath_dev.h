@@ -51,7 +51,28 @@ PT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // v_min_f32 / v_max_f32: IEEE minNum/maxNum, -0 < +0.
 PT_DEV float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 PT_DEV float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
-PT_DEV float sqrt_(float a) { return __builtin_sqrtf(a); }
+// Division contract: x / y = x * rcp_(y), where rcp_ is the correctly rounded reciprocal that treats a
+// subnormal y as a zero of its sign and replaces a subnormal result by a zero of its sign (WGSL bounds x / y
+// to 2.5 ULP for |y| in [2^-126, 2^126] and allows flushing).  That is exactly what the hardware estimate
+// (1 ulp, flushing) plus one fused Newton step plus v_div_fixup gives: 4 instructions instead of the 11 of
+// an IEEE divide.  ptx_kat_exhaustive (ptx355.hip) checks it against the definition over all 2^32 inputs.
+PT_DEV float rcp_(float y) {
+    float r = __builtin_amdgcn_rcpf(y);
+    float e = __builtin_fmaf(-y, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return __builtin_amdgcn_div_fixupf(r, y, 1.0f);
+}
+PT_DEV float div_(float x, float y) { return x * rcp_(y); }
+// Correctly rounded IEEE square root.  For 2^-102 <= x < inf the reciprocal-square-root estimate plus one
+// fused residual step is correctly rounded (same exhaustive check); the rest (zeros, subnormal and tiny
+// inputs whose residual would underflow, infinity, NaN, negative inputs) takes the compiler's long sequence.
+PT_DEV float sqrt_(float x) {
+    if (__builtin_expect((__float_as_uint(x) - 0x0C800000u) >= (0x7F800000u - 0x0C800000u), 0)) return __builtin_sqrtf(x);
+    float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r, h = 0.5f * r;
+    float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
 PT_DEV float abs_(float a) { return __builtin_fabsf(a); }
 
 #define DM_PIO2 1.57079632679489661923f
@@ -86,7 +107,7 @@ PT_DEV float atan2_(float y, float x) {
     bool big = mn > 0.4142135623730950f * mx;
     float num = big ? mn - mx : mn;
     float den = big ? mn + mx : mx;
-    float t = num / den;
+    float t = div_(num, den);
     float z = t * t;
     float p = fma_(z, fma_(z, fma_(z, 8.05374449538e-2f, -1.38776856032e-1f), 1.99777106478e-1f), -3.33329491539e-1f);
     float r = fma_(p * z, t, t);
@@ -193,8 +214,7 @@ PT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 PT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
-PT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
-PT_DEV V3 operator/(V3 a, V3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PT_DEV V3 operator/(V3 a, V3 b) { return v3(dm::div_(a.x, b.x), dm::div_(a.y, b.y), dm::div_(a.z, b.z)); }
 PT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 PT_DEV float dot(V3 a, V3 b) { return dm::fma_(a.z, b.z, dm::fma_(a.y, b.y, a.x * b.x)); }
 PT_DEV float dot2(float ax, float ay, float bx, float by) { return dm::fma_(ay, by, ax * bx); }
@@ -204,13 +224,13 @@ PT_DEV V3 cross(V3 a, V3 b) {
 }
 PT_DEV V3 madd(V3 o, V3 d, float t) { return v3(dm::fma_(d.x, t, o.x), dm::fma_(d.y, t, o.y), dm::fma_(d.z, t, o.z)); }
 PT_DEV float length(V3 a) { return dm::sqrt_(dot(a, a)); }
-PT_DEV V3 normalize(V3 a) { float inv = 1.0f / dm::sqrt_(dot(a, a)); return a * inv; }
+PT_DEV V3 normalize(V3 a) { float inv = dm::rcp_(dm::sqrt_(dot(a, a))); return a * inv; }
 // vector / scalar = vector * (1 / scalar): one correctly rounded reciprocal, then three multiplies.
-PT_DEV V3 vdivs(V3 a, float s) { float inv = 1.0f / s; return a * inv; }
+PT_DEV V3 vdivs(V3 a, float s) { float inv = dm::rcp_(s); return a * inv; }
 PT_DEV V3 vabs(V3 a) { return v3(dm::abs_(a.x), dm::abs_(a.y), dm::abs_(a.z)); }
 PT_DEV V3 vmin(V3 a, V3 b) { return v3(dm::fmin_(a.x, b.x), dm::fmin_(a.y, b.y), dm::fmin_(a.z, b.z)); }
 PT_DEV V3 vmax(V3 a, V3 b) { return v3(dm::fmax_(a.x, b.x), dm::fmax_(a.y, b.y), dm::fmax_(a.z, b.z)); }
-PT_DEV V3 vrcp(V3 a) { return v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
+PT_DEV V3 vrcp(V3 a) { return v3(dm::rcp_(a.x), dm::rcp_(a.y), dm::rcp_(a.z)); }
 PT_DEV float clampf(float x, float lo, float hi) { return dm::fmin_(dm::fmax_(x, lo), hi); }
 PT_DEV float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 PT_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }

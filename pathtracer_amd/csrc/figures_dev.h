@@ -13,14 +13,14 @@ struct HitFull { V3 pos, normal; V2 uv; };
 
 PT_DEV V2 sphere_uv(V3 d) {  // sphere.wgsl:34-37
     V2 r;
-    r.x = 0.5f + dm::atan2_(d.z, d.x) / PT_TWO_PI;
-    r.y = 0.5f - dm::asin_(clampf(d.y, -1.0f, 1.0f)) / PT_PI;
+    r.x = 0.5f + dm::atan2_(d.z, d.x) * (1.0f / PT_TWO_PI);
+    r.y = 0.5f - dm::asin_(clampf(d.y, -1.0f, 1.0f)) * (1.0f / PT_PI);
     return r;
 }
 struct Onb { V3 u, v, n; };
 PT_DEV Onb build_onb(V3 n) {  // utils.wgsl:6-13
     float s = n.z >= 0.0f ? 1.0f : -1.0f;
-    float a = -1.0f / (s + n.z);
+    float a = dm::div_(-1.0f, s + n.z);
     float b = n.x * n.y * a;
     Onb o;
     o.u = v3(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
@@ -61,7 +61,7 @@ PT_DEV bool isect_plane(const Ray& ray, const DPrim& g, float& t_out, HitFull* h
     V3 pos = v3p(g.p), n = v3p(g.p + 3);
     float denom = dot(n, ray.d);
     if (dm::abs_(denom) < PT_EPS) return false;
-    float t = dot(pos - ray.o, n) / denom;
+    float t = dm::div_(dot(pos - ray.o, n), denom);
     if (t < PT_EPS) return false;
     t_out = t;
     if (FULL) {
@@ -120,7 +120,7 @@ PT_DEV bool isect_cylinder(const Ray& ray, const DPrim& g, float& t_out, HitFull
     float disc = dm::fma_(half_b, half_b, -(a * c));
     if (disc < 0.0f) return false;
     float sqrtd = dm::sqrt_(disc);
-    float inv_a = 1.0f / a;
+    float inv_a = dm::rcp_(a);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         float t = i == 0 ? (-half_b - sqrtd) * inv_a : (-half_b + sqrtd) * inv_a;
@@ -134,8 +134,8 @@ PT_DEV bool isect_cylinder(const Ray& ray, const DPrim& g, float& t_out, HitFull
                 h->normal = normalize((p - pos) - axis * proj);
                 if (need_uv) {
                     float angle = dm::atan2_(h->normal.z, h->normal.x);
-                    h->uv.x = angle / PT_TWO_PI + 0.5f;
-                    h->uv.y = (proj + half_h) / height;
+                    h->uv.x = angle * (1.0f / PT_TWO_PI) + 0.5f;
+                    h->uv.y = dm::div_(proj + half_h, height);
                 }
             }
             return true;
@@ -149,7 +149,7 @@ PT_DEV bool isect_cylinder(const Ray& ray, const DPrim& g, float& t_out, HitFull
         for (int si = 0; si < 2; si++) {
             float cap_sign = si == 1 ? -1.0f : 1.0f;
             V3 cap_center = pos + axis * half_h * cap_sign;
-            float t = dot(cap_center - ray.o, axis * cap_sign) / (d_axis * cap_sign);
+            float t = dm::div_(dot(cap_center - ray.o, axis * cap_sign), d_axis * cap_sign);
             if (t > PT_EPS && t < best) {
                 V3 p = madd(ray.o, ray.d, t);
                 V3 off = p - cap_center;
@@ -159,8 +159,8 @@ PT_DEV bool isect_cylinder(const Ray& ray, const DPrim& g, float& t_out, HitFull
                     if (FULL) {
                         h->pos = p;
                         h->normal = axis * cap_sign;
-                        h->uv.x = (off.x / radius + 1.0f) * 0.5f;
-                        h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+                        h->uv.x = (dm::div_(off.x, radius) + 1.0f) * 0.5f;
+                        h->uv.y = (dm::div_(off.z, radius) + 1.0f) * 0.5f;
                     }
                 }
             }
@@ -177,14 +177,14 @@ PT_DEV bool isect_cone(const Ray& ray, const DPrim& g, float& t_out, HitFull* h,
     V3 oc = ray.o - apex;
     float d_dot_v = dot(ray.d, axis);
     float oc_dot_v = dot(oc, axis);
-    float cos2 = 1.0f / (1.0f + tan2);
+    float cos2 = dm::rcp_(1.0f + tan2);
     float a_c = dm::fma_(d_dot_v, d_dot_v, -(cos2 * dot(ray.d, ray.d)));
     float b_c = dm::fma_(d_dot_v, oc_dot_v, -(cos2 * dot(ray.d, oc)));
     float c_c = dm::fma_(oc_dot_v, oc_dot_v, -(cos2 * dot(oc, oc)));
     float disc = dm::fma_(b_c, b_c, -(a_c * c_c));
     if (disc < 0.0f) return false;
     float sqrtd = dm::sqrt_(disc);
-    float inv_a = 1.0f / a_c;
+    float inv_a = dm::rcp_(a_c);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         float t = i == 0 ? (-b_c - sqrtd) * inv_a : (-b_c + sqrtd) * inv_a;
@@ -200,8 +200,8 @@ PT_DEV bool isect_cone(const Ray& ray, const DPrim& g, float& t_out, HitFull* h,
                 h->normal = normalize(to_p - axis * n_proj * (1.0f + tan2));
                 if (need_uv) {
                     float angle = dm::atan2_(h->normal.z, h->normal.x);
-                    h->uv.x = angle / PT_TWO_PI + 0.5f;
-                    h->uv.y = -proj / height;
+                    h->uv.x = angle * (1.0f / PT_TWO_PI) + 0.5f;
+                    h->uv.y = dm::div_(-proj, height);
                 }
             }
             return true;
@@ -209,7 +209,7 @@ PT_DEV bool isect_cone(const Ray& ray, const DPrim& g, float& t_out, HitFull* h,
     }
     float d_axis2 = dot(ray.d, axis);
     if (dm::abs_(d_axis2) > PT_EPS) {
-        float t = dot(pos - ray.o, axis) / d_axis2;
+        float t = dm::div_(dot(pos - ray.o, axis), d_axis2);
         if (t > PT_EPS && t < PT_MAX_T) {
             V3 p = madd(ray.o, ray.d, t);
             V3 off = p - pos;
@@ -218,8 +218,8 @@ PT_DEV bool isect_cone(const Ray& ray, const DPrim& g, float& t_out, HitFull* h,
                 if (FULL) {
                     h->pos = p;
                     h->normal = -axis;
-                    h->uv.x = (off.x / radius + 1.0f) * 0.5f;
-                    h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+                    h->uv.x = (dm::div_(off.x, radius) + 1.0f) * 0.5f;
+                    h->uv.y = (dm::div_(off.z, radius) + 1.0f) * 0.5f;
                 }
                 return true;
             }
@@ -233,7 +233,7 @@ PT_DEV bool isect_disc(const Ray& ray, const DPrim& g, float& t_out, HitFull* h)
     float radius = g.p[6];
     float denom = dot(n, ray.d);
     if (dm::abs_(denom) < PT_EPS) return false;
-    float t = dot(pos - ray.o, n) / denom;
+    float t = dm::div_(dot(pos - ray.o, n), denom);
     if (t < PT_EPS) return false;
     V3 p = madd(ray.o, ray.d, t);
     V3 off = p - pos;
@@ -242,8 +242,8 @@ PT_DEV bool isect_disc(const Ray& ray, const DPrim& g, float& t_out, HitFull* h)
     if (FULL) {
         h->pos = p;
         h->normal = denom < 0.0f ? n : -n;
-        h->uv.x = (off.x / radius + 1.0f) * 0.5f;
-        h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+        h->uv.x = (dm::div_(off.x, radius) + 1.0f) * 0.5f;
+        h->uv.y = (dm::div_(off.z, radius) + 1.0f) * 0.5f;
     }
     return true;
 }
@@ -252,7 +252,7 @@ PT_DEV bool mt_core(const Ray& ray, V3 v0, V3 e1, V3 e2, float& t, float& u, flo
     V3 hh = cross(ray.d, e2);
     float a = dot(e1, hh);
     if (dm::abs_(a) < PT_EPS) return false;
-    float fi = 1.0f / a;
+    float fi = dm::rcp_(a);
     V3 s = ray.o - v0;
     u = fi * dot(s, hh);
     if (u < 0.0f || u > 1.0f) return false;
@@ -379,7 +379,7 @@ PT_DEV bool isect_ellipsoid(const Ray& ray, const DPrim& g, float& t_out, HitFul
     float disc = dm::fma_(half_b, half_b, -(a * c));
     if (disc < 0.0f) return false;
     float sqrtd = dm::sqrt_(disc);
-    float inv_a = 1.0f / a;
+    float inv_a = dm::rcp_(a);
     float t = (-half_b - sqrtd) * inv_a;
     if (t < PT_EPS) {
         t = (-half_b + sqrtd) * inv_a;
@@ -405,7 +405,7 @@ PT_DEV bool isect_paraboloid(const Ray& ray, const DPrim& g, float& t_out, HitFu
     float disc = dm::fma_(b, b, -(4.0f * a * c));
     if (disc < 0.0f) return false;
     float sqrtd = dm::sqrt_(disc);
-    float inv_2a = 0.5f / a;
+    float inv_2a = dm::div_(0.5f, a);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         float t = i == 0 ? (-b - sqrtd) * inv_2a : (-b + sqrtd) * inv_2a;
@@ -420,8 +420,8 @@ PT_DEV bool isect_paraboloid(const Ray& ray, const DPrim& g, float& t_out, HitFu
                 h->normal = normalize(v3(2.0f * local.x, -r, 2.0f * local.z));
                 if (need_uv) {
                     float angle = dm::atan2_(local.z, local.x);
-                    h->uv.x = angle / PT_TWO_PI + 0.5f;
-                    h->uv.y = local_y / hh;
+                    h->uv.x = angle * (1.0f / PT_TWO_PI) + 0.5f;
+                    h->uv.y = dm::div_(local_y, hh);
                 }
             }
             return true;
@@ -430,7 +430,7 @@ PT_DEV bool isect_paraboloid(const Ray& ray, const DPrim& g, float& t_out, HitFu
     float d_y = d.y;
     if (dm::abs_(d_y) > PT_EPS) {
         float cap_y = pos.y + hh;
-        float t = (cap_y - ray.o.y) / d_y;
+        float t = dm::div_(cap_y - ray.o.y, d_y);
         if (t > PT_EPS) {
             V3 p = madd(ray.o, d, t);
             V3 local = p - pos;
@@ -441,8 +441,8 @@ PT_DEV bool isect_paraboloid(const Ray& ray, const DPrim& g, float& t_out, HitFu
                     h->pos = p;
                     h->normal = v3(0.0f, 1.0f, 0.0f);
                     float s = dm::sqrt_(r * hh);
-                    h->uv.x = local.x / s * 0.5f + 0.5f;
-                    h->uv.y = local.z / s * 0.5f + 0.5f;
+                    h->uv.x = dm::div_(local.x, s) * 0.5f + 0.5f;
+                    h->uv.y = dm::div_(local.z, s) * 0.5f + 0.5f;
                 }
                 return true;
             }
@@ -456,7 +456,7 @@ PT_DEV bool isect_hyperboloid(const Ray& ray, const DPrim& g, float& t_out, HitF
     float r = g.p[3], height = g.p[4];
     V3 oc = ray.o - pos, d = ray.d;
     float half_h = height * 0.5f;
-    float inv_r2 = 1.0f / (r * r);
+    float inv_r2 = dm::rcp_(r * r);
     float a = (dot2(d.x, d.z, d.x, d.z) - d.y * d.y) * inv_r2;
     float b = 2.0f * (dot2(oc.x, oc.z, d.x, d.z) - oc.y * d.y) * inv_r2;
     float c = (dot2(oc.x, oc.z, oc.x, oc.z) - oc.y * oc.y) * inv_r2 - 1.0f;
@@ -465,7 +465,7 @@ PT_DEV bool isect_hyperboloid(const Ray& ray, const DPrim& g, float& t_out, HitF
     float best = PT_MAX_T;
     if (disc >= 0.0f) {
         float sqrtd = dm::sqrt_(disc);
-        float inv_2a = 0.5f / a;
+        float inv_2a = dm::div_(0.5f, a);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             float t = i == 0 ? (-b - sqrtd) * inv_2a : (-b + sqrtd) * inv_2a;
@@ -481,8 +481,8 @@ PT_DEV bool isect_hyperboloid(const Ray& ray, const DPrim& g, float& t_out, HitF
                     h->normal = normalize(v3(2.0f * local.x, -2.0f * local.y, 2.0f * local.z) * inv_r2);
                     if (need_uv) {
                         float angle = dm::atan2_(local.z, local.x);
-                        h->uv.x = angle / PT_TWO_PI + 0.5f;
-                        h->uv.y = (local_y + half_h) / height;
+                        h->uv.x = angle * (1.0f / PT_TWO_PI) + 0.5f;
+                        h->uv.y = dm::div_(local_y + half_h, height);
                     }
                 }
             }
@@ -492,7 +492,7 @@ PT_DEV bool isect_hyperboloid(const Ray& ray, const DPrim& g, float& t_out, HitF
     for (int cap = 0; cap < 2; cap++) {
         float cap_y = pos.y + (cap == 1 ? half_h : -half_h);
         if (dm::abs_(d.y) > PT_EPS) {
-            float t = (cap_y - ray.o.y) / d.y;
+            float t = dm::div_(cap_y - ray.o.y, d.y);
             if (t > PT_EPS && t < best) {
                 V3 p = madd(ray.o, d, t);
                 V3 local = p - pos;
@@ -505,8 +505,8 @@ PT_DEV bool isect_hyperboloid(const Ray& ray, const DPrim& g, float& t_out, HitF
                         h->pos = p;
                         h->normal = cap == 1 ? v3(0.0f, 1.0f, 0.0f) : v3(0.0f, -1.0f, 0.0f);
                         float s = dm::sqrt_(cap_r2);
-                        h->uv.x = local.x / s * 0.5f + 0.5f;
-                        h->uv.y = local.z / s * 0.5f + 0.5f;
+                        h->uv.x = dm::div_(local.x, s) * 0.5f + 0.5f;
+                        h->uv.y = dm::div_(local.z, s) * 0.5f + 0.5f;
                     }
                 }
             }
@@ -566,7 +566,7 @@ PT_DEV float sdf_mandelbulb(V3 p, float power, int max_iter) {  // mandelbulb.wg
     for (int i = 0; i < max_iter; i++) {
         dz = dm::fma_(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
         float r = dm::sqrt_(m);
-        float b = power * dm::acos_(clampf(w.y / r, -1.0f, 1.0f));
+        float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
         float a = power * dm::atan2_(w.x, w.z);
         float rp = dm::pow_(r, power);
         float sb, cb, sa, ca;
@@ -577,7 +577,7 @@ PT_DEV float sdf_mandelbulb(V3 p, float power, int max_iter) {  // mandelbulb.wg
         if (m > 256.0f) break;
     }
     float r = dm::sqrt_(m);
-    return 0.25f * dm::log_(m) * r / dz;
+    return dm::div_(0.25f * dm::log_(m) * r, dz);
 }
 PT_DEV V4 quat_mult(V4 a, V4 b) {  // julia.wgsl:4-11
     V4 r;
@@ -601,7 +601,7 @@ PT_DEV float sdf_julia(V3 p, V4 cc, int max_iter) {  // julia.wgsl:13-32
     }
     float r = dm::sqrt_(r2);
     float dr = dm::sqrt_(dot4(dz, dz));
-    return 0.5f * r * dm::log_(r) / dr;
+    return dm::div_(0.5f * r * dm::log_(r), dr);
 }
 
 // Evaluates the figure's distance field at a point given in the space its marcher steps in.
@@ -670,8 +670,8 @@ PT_DEV void finish_torus(const Ray& ray, const DPrim& g, float t, HitFull* h, bo
         float angle_major = dm::atan2_(local.z, local.x);
         float px = dm::sqrt_(dot2(local.x, local.z, local.x, local.z)) - g.p[3];
         float angle_minor = dm::atan2_(local.y, px);
-        h->uv.x = angle_major / PT_TWO_PI + 0.5f;
-        h->uv.y = angle_minor / PT_TWO_PI + 0.5f;
+        h->uv.x = angle_major * (1.0f / PT_TWO_PI) + 0.5f;
+        h->uv.y = angle_minor * (1.0f / PT_TWO_PI) + 0.5f;
     }
 }
 // mebius.wgsl:38-87
@@ -704,7 +704,7 @@ PT_DEV void finish_mebius(const Ray& ray, const DPrim& g, float t, HitFull* h, b
     h->normal = tet_normal<false>(g, local, 0.5773f * PT_EPS * 2.0f);
     if (need_uv) {
         float angle = dm::atan2_(local.z, local.x);
-        h->uv.x = angle / PT_TWO_PI + 0.5f;
+        h->uv.x = angle * (1.0f / PT_TWO_PI) + 0.5f;
         h->uv.y = 0.5f;
     }
 }
@@ -719,7 +719,7 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
     float disc = dm::fma_(b, b, -cs);
     if (disc < 0.0f) return false;
     const float omega = 1.3f;
-    const float inv_radius = 1.0f / radius;
+    const float inv_radius = dm::rcp_(radius);
     float sq = dm::sqrt_(disc);
     float t = dm::fmax_(-b - sq, PT_EPS);
     float max_t = -b + sq;
@@ -746,7 +746,7 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
 PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) {
     V3 pos = v3p(g.p);
     h->pos = madd(ray.o, ray.d, t);
-    V3 local = (h->pos - pos) * (1.0f / g.p[3]);
+    V3 local = (h->pos - pos) * (dm::rcp_(g.p[3]));
     h->normal = tet_normal<true>(g, local, 0.5773f * PT_EPS * 2.0f);
     h->uv.x = 0.0f;
     h->uv.y = 0.0f;
@@ -833,8 +833,8 @@ PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, uin
             h->normal = denom < 0.0f ? n : -n;
             if (need_uv) {
                 V3 off = h->pos - pos;
-                h->uv.x = (off.x / radius + 1.0f) * 0.5f;
-                h->uv.y = (off.z / radius + 1.0f) * 0.5f;
+                h->uv.x = (dm::div_(off.x, radius) + 1.0f) * 0.5f;
+                h->uv.y = (dm::div_(off.z, radius) + 1.0f) * 0.5f;
             }
             break;
         }

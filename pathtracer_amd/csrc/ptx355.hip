@@ -255,11 +255,31 @@ extern "C" __global__ void ptx_kat_math_kernel(int op, uint32_t n, const float* 
         case 9: r = dm::fmin_(x, y); break;
         case 10: r = dm::fmax_(x, y); break;
         case 11: r = dm::sqrt_(x); break;
-        case 12: r = x / y; break;
+        case 12: r = dm::div_(x, y); break;
         case 13: r = dm::fma_(x, y, x); break;
+        case 14: r = dm::rcp_(x); break;
         default: break;
     }
     out[i] = r;
+}
+
+// Exhaustive check of the short reciprocal / square-root sequences: every one of the 2^32 inputs against the
+// definition (division contract in dmath_dev.h) evaluated with the compiler's IEEE divide and square root.
+PT_DEV float rcp_definition(float y) {
+    if (y != y) return y;
+    const uint32_t sign = __float_as_uint(y) & 0x80000000u;
+    if (dm::abs_(y) < 1.17549435e-38f) return __uint_as_float(sign | 0x7f800000u);
+    float r = 1.0f / y;
+    if (dm::abs_(r) < 1.17549435e-38f) return __uint_as_float(sign);
+    return r;
+}
+extern "C" __global__ void ptx_kat_exhaustive_kernel(int op, uint32_t hi, unsigned long long* n_bad, uint32_t* first_bad) {
+    const uint32_t bits = (hi << 24) | (blockIdx.x * blockDim.x + threadIdx.x);
+    const float x = __uint_as_float(bits);
+    const float got = op == 0 ? dm::rcp_(x) : dm::sqrt_(x);
+    const float want = op == 0 ? rcp_definition(x) : __builtin_sqrtf(x);
+    const bool same = (got != got && want != want) || __float_as_uint(got) == __float_as_uint(want);
+    if (!same && atomicAdd(n_bad, 1ull) == 0ull) *first_bad = bits;
 }
 
 // Unit hook: one ray per lane through the same traversal code as the render kernels (WALK as they pick it).
@@ -453,6 +473,21 @@ void ptx_destroy(ptx_ctx* c) {
 
 const char* ptx_last_error(const ptx_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// The division contract's reciprocal (dmath_dev.h) for values precomputed on the host.
+static float host_rcp(float y) {
+    if (y != y) return y;
+    uint32_t b;
+    memcpy(&b, &y, 4);
+    const uint32_t sign = b & 0x80000000u, inf = sign | 0x7f800000u;
+    float r;
+    if ((b & 0x7f800000u) == 0u) { memcpy(&r, &inf, 4); return r; }
+    volatile float q = 1.0f / y;
+    r = q;
+    memcpy(&b, &r, 4);
+    if ((b & 0x7f800000u) == 0u) memcpy(&r, &sign, 4);
+    return r;
+}
+
 int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx_material* mats, uint32_t nmat,
                      const ptx_bvh_node* nodes, uint32_t nnode, const uint32_t* prims, uint32_t nprim,
                      const uint32_t* lights, uint32_t nlight, const uint32_t* infinite, uint32_t ninf,
@@ -520,7 +555,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
         volatile float a = 4.0f * PT_PI;  // lighting.wgsl:24: 4.0 * PI * r * r, left to right
         a = a * f.radius;
         a = a * f.radius;
-        volatile float pdf = 1.0f / a;
+        volatile float pdf = host_rcp(a);
         L.area_pdf = pdf;
         dl.push_back(L);
     }
@@ -858,6 +893,30 @@ int ptx_kat_math(ptx_ctx* c, int op, uint32_t n, const float* a, const float* b,
     if (da) (void)hipFree(da);
     if (db) (void)hipFree(db);
     if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+int ptx_kat_exhaustive(ptx_ctx* c, int op, uint64_t* n_bad, uint32_t* first_bad) {
+    if (!c || !n_bad || !first_bad || (op != 0 && op != 1)) return PTX_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* dn = nullptr;
+    uint32_t* df = nullptr;
+    int rc = PTX_OK;
+    if (hipMalloc((void**)&dn, 8) != hipSuccess || hipMalloc((void**)&df, 4) != hipSuccess) {
+        rc = fail(c, PTX_ERR_OOM, "ptx_kat_exhaustive: hipMalloc");
+    } else {
+        (void)hipMemsetAsync(dn, 0, 8, c->stream);
+        (void)hipMemsetAsync(df, 0, 4, c->stream);
+        for (uint32_t hi = 0; hi < 256u; hi++)
+            hipLaunchKernelGGL(ptx_kat_exhaustive_kernel, dim3(1u << 16), dim3(256), 0, c->stream, op, hi, dn, df);
+        unsigned long long nb = 0;
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&nb, dn, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(first_bad, df, 4, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(c, PTX_ERR_HIP, "ptx_kat_exhaustive: kernel or copy out");
+        *n_bad = nb;
+    }
+    if (dn) (void)hipFree(dn);
+    if (df) (void)hipFree(df);
     return rc;
 }
 

@@ -212,7 +212,7 @@ PT_DEV bool is_inside_neg(const DNeg& f, V3 p) {
             V3 oc = p - apex;
             float proj = dot(oc, n);
             if (proj > 0.0f || proj < -f.height) return false;
-            float cos2 = 1.0f / (1.0f + f.radius2);
+            float cos2 = dm::rcp_(1.0f + f.radius2);
             float r2 = dot(oc, oc);
             return proj * proj > cos2 * r2;
         }
@@ -252,11 +252,11 @@ PT_DEV float find_exit_t(const DNeg& f, const Ray& ray) {
             float cc = dot(oc_perp, oc_perp) - f.radius * f.radius;
             float disc = dm::fma_(half_b, half_b, -(a * cc));
             if (disc < 0.0f) return PT_MAX_T;
-            float t_far = (-half_b + dm::sqrt_(disc)) / a;
+            float t_far = dm::div_(-half_b + dm::sqrt_(disc), a);
             float d_axis = dot(ray.d, axis);
             if (dm::abs_(d_axis) > PT_EPS) {
-                float t_top = (half_h - dot(oc, axis)) / d_axis;
-                float t_bot = (-half_h - dot(oc, axis)) / d_axis;
+                float t_top = dm::div_(half_h - dot(oc, axis), d_axis);
+                float t_bot = dm::div_(-half_h - dot(oc, axis), d_axis);
                 return dm::fmin_(t_far, dm::fmax_(t_top, t_bot));
             }
             return t_far;
@@ -264,7 +264,7 @@ PT_DEV float find_exit_t(const DNeg& f, const Ray& ray) {
         case FIG_CONE: {
             V3 apex = pos + axis * f.height;
             V3 oc = ray.o - apex;
-            float cos2 = 1.0f / (1.0f + f.radius2);
+            float cos2 = dm::rcp_(1.0f + f.radius2);
             float d_dot_v = dot(ray.d, axis);
             float oc_dot_v = dot(oc, axis);
             float a_c = dm::fma_(d_dot_v, d_dot_v, -(cos2 * dot(ray.d, ray.d)));
@@ -272,7 +272,7 @@ PT_DEV float find_exit_t(const DNeg& f, const Ray& ray) {
             float c_c = dm::fma_(oc_dot_v, oc_dot_v, -(cos2 * dot(oc, oc)));
             float disc = dm::fma_(b_c, b_c, -(a_c * c_c));
             if (disc < 0.0f) return PT_MAX_T;
-            return (-b_c + dm::sqrt_(disc)) / a_c;
+            return dm::div_(-b_c + dm::sqrt_(disc), a_c);
         }
         default: return PT_MAX_T;
     }
@@ -445,7 +445,7 @@ PT_DEV V3 sample_texture(const DScene& sc, int32_t texture_id, V2 uv) {
     py = py < info.height - 1u ? py : info.height - 1u;
     uint32_t idx = info.offset + py * info.width + px;
     uint32_t packed = idx < sc.npix ? sc.tex_pixels[idx] : 0u;
-    return v3((float)(packed & 0xFFu) / 255.0f, (float)((packed >> 8) & 0xFFu) / 255.0f, (float)((packed >> 16) & 0xFFu) / 255.0f);
+    return v3((float)(packed & 0xFFu) * (1.0f / 255.0f), (float)((packed >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((packed >> 16) & 0xFFu) * (1.0f / 255.0f));
 }
 // skybox.wgsl:6-27
 PT_DEV V3 sample_skybox(const DScene& sc, const ptx_camera& cam, V3 dir) {
@@ -470,12 +470,12 @@ PT_DEV V3 refract_vec(V3 v, V3 n, float eta) {
 PT_DEV float ggx_ndf(float n_dot_h, float alpha) {
     float a2 = alpha * alpha;
     float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
-    return a2 / (PT_PI * denom * denom);
+    return dm::div_(a2, PT_PI * denom * denom);
 }
 PT_DEV float ggx_g1(float n_dot_v, float alpha) {
     float a2 = alpha * alpha;
     float denom = n_dot_v + dm::sqrt_(a2 + (1.0f - a2) * n_dot_v * n_dot_v);
-    return 2.0f * n_dot_v / denom;
+    return dm::div_(2.0f * n_dot_v, denom);
 }
 struct MatD { V3 base_color; float metallic, roughness, ior; };
 PT_DEV V3 eval_brdf(V3 wo, V3 wi, V3 n, const MatD& mat) {  // materials.wgsl:65-90
@@ -515,7 +515,7 @@ PT_DEV bool sample_brdf(uint32_t& rng, V3 wo, V3 n, const MatD& mat, V3& wi_out,
     Onb onb = build_onb(n);
     if (pick < spec_prob) {
         float a2 = alpha * alpha;  // materials.wgsl:38-49
-        float cos_theta = dm::sqrt_((1.0f - ry) / (1.0f + (a2 - 1.0f) * ry));
+        float cos_theta = dm::sqrt_(dm::div_(1.0f - ry, 1.0f + (a2 - 1.0f) * ry));
         float sin_theta = dm::sqrt_(1.0f - cos_theta * cos_theta);
         h = normalize(onb_mul(onb, v3(sin_theta * cp, sin_theta * sp, cos_theta)));
         wi = reflect_vec(-wo, h);
@@ -532,7 +532,7 @@ PT_DEV bool sample_brdf(uint32_t& rng, V3 wo, V3 n, const MatD& mat, V3& wi_out,
     float n_dot_h = dm::fmax_(dot(n, h), 0.0f);
     float v_dot_h = dm::fmax_(dot(wo, h), 0.0f);
     V3 brdf = eval_brdf(wo, wi, n, mat);
-    float spec_pdf = ggx_ndf(n_dot_h, alpha) * n_dot_h / (4.0f * v_dot_h);
+    float spec_pdf = dm::div_(ggx_ndf(n_dot_h, alpha) * n_dot_h, 4.0f * v_dot_h);
     float diff_pdf = n_dot_l * PT_INV_PI;
     float pdf = spec_prob * spec_pdf + (1.0f - spec_prob) * diff_pdf;
     pdf = dm::fmax_(pdf, PT_EPS);
@@ -546,9 +546,9 @@ PT_DEV bool sample_brdf(uint32_t& rng, V3 wo, V3 n, const MatD& mat, V3& wi_out,
 PT_DEV bool sample_glass(uint32_t& rng, V3 wo, V3 n, float ior, V3& dir_out) {
     bool entering = dot(wo, n) > 0.0f;
     V3 face_n = entering ? n : -n;
-    float eta = entering ? 1.0f / ior : ior / 1.0f;
+    float eta = entering ? dm::rcp_(ior) : ior;  // ior / 1.0
     float cos_i = dm::abs_(dot(wo, face_n));
-    float r0 = (1.0f - ior) / (1.0f + ior);  // utils.wgsl:51-57
+    float r0 = dm::div_(1.0f - ior, 1.0f + ior);  // utils.wgsl:51-57
     r0 = r0 * r0;
     float tt = 1.0f - cos_i;
     float t2 = tt * tt;
@@ -567,10 +567,10 @@ PT_DEV bool sample_glass(uint32_t& rng, V3 wo, V3 n, float ior, V3& dir_out) {
 }
 
 // ---- tonemap.wgsl --------------------------------------------------------------------------------
-PT_DEV float aces_c(float x) { return clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f); }
+PT_DEV float aces_c(float x) { return clampf(dm::div_(x * (2.51f * x + 0.03f), x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f); }
 PT_DEV float linear_to_srgb(float c) {
     float lo = c * 12.92f;
-    float hi = 1.055f * dm::pow_(c, 1.0f / 2.4f) - 0.055f;
+    float hi = 1.055f * dm::pow_(c, (1.0f / 2.4f)) - 0.055f;
     return c <= 0.0031308f ? lo : hi;
 }
 PT_DEV uint32_t unorm8(float v) {
@@ -581,7 +581,7 @@ PT_DEV uint32_t unorm8(float v) {
 PT_DEV uint32_t tonemap_rgba8(const ptx_camera& cam, V3 color) {  // tonemap.wgsl:27-42 + rgba8unorm store
     V3 e = color * cam.exposure;
     V3 m;
-    if (cam.tone_mapper == 1u) m = v3(e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z));
+    if (cam.tone_mapper == 1u) m = v3(dm::div_(e.x, 1.0f + e.x), dm::div_(e.y, 1.0f + e.y), dm::div_(e.z, 1.0f + e.z));
     else if (cam.tone_mapper == 2u) m = v3(clampf(e.x, 0.0f, 1.0f), clampf(e.y, 0.0f, 1.0f), clampf(e.z, 0.0f, 1.0f));
     else m = v3(aces_c(e.x), aces_c(e.y), aces_c(e.z));
     return unorm8(linear_to_srgb(m.x)) | (unorm8(linear_to_srgb(m.y)) << 8) | (unorm8(linear_to_srgb(m.z)) << 16) | 0xFF000000u;
@@ -591,8 +591,8 @@ PT_DEV uint32_t tonemap_rgba8(const ptx_camera& cam, V3 color) {  // tonemap.wgs
 PT_DEV Ray generate_ray(const ptx_camera& cam, uint32_t& rng, float fx, float fy) {
     float jx = rand_f32(rng) - 0.5f, jy = rand_f32(rng) - 0.5f;
     float px = fx + jx, py = fy + jy;
-    float ndc_x = (2.0f * px / (float)cam.width - 1.0f) * cam.aspect;
-    float ndc_y = 1.0f - 2.0f * py / (float)cam.height;
+    float ndc_x = (dm::div_(2.0f * px, (float)cam.width) - 1.0f) * cam.aspect;
+    float ndc_y = 1.0f - dm::div_(2.0f * py, (float)cam.height);
     Ray r;
     r.d = normalize(v3p(cam.right) * ndc_x + v3p(cam.up) * ndc_y + v3p(cam.forward) * cam.focal_length);
     r.o = v3p(cam.position);
@@ -712,12 +712,12 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
                 PT_SITE(34);
                 V3 light_normal = normalize(light_point - lpos);
                 float cos_light = dm::abs_(dot(-light_dir, light_normal));
-                float light_solid_pdf = cos_light <= 0.0f ? 0.0f : L.area_pdf * (light_dist * light_dist) / cos_light;
+                float light_solid_pdf = cos_light <= 0.0f ? 0.0f : dm::div_(L.area_pdf * (light_dist * light_dist), cos_light);
                 V3 brdf = eval_brdf(wo, light_dir, n, mat);
                 float brdf_pdf_val = n_dot_l * PT_INV_PI;
                 float pa = light_solid_pdf * (float)num_lights;
                 float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
-                float w = a2 / dm::fmax_(a2 + b2, 1e-10f);
+                float w = dm::div_(a2, dm::fmax_(a2 + b2, 1e-10f));
                 V3 contrib = vdivs(ps.throughput * v3p(L.le) * brdf * n_dot_l * w, pa);
                 const bool lit = light_solid_pdf > 0.0f;
                 Ray sray;
@@ -764,7 +764,7 @@ PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, 
         ps.throughput = vdivs(ps.throughput, survival);
     }
     float lum = dot(ps.throughput, v3(0.2126f, 0.7152f, 0.0722f));
-    if (lum > cam.firefly_clamp) ps.throughput = ps.throughput * (cam.firefly_clamp / lum);
+    if (lum > cam.firefly_clamp) ps.throughput = ps.throughput * (dm::div_(cam.firefly_clamp, lum));
     ps.bounce += 1u;
     return false;
 }

@@ -147,7 +147,13 @@ class PathTracer:
         return float(ms.value), int(n.value)
 
     KAT_OPS = {"sin": 0, "cos": 1, "asin": 2, "acos": 3, "log": 4, "log2": 5, "exp2": 6, "atan2": 7, "pow": 8,
-               "min": 9, "max": 10, "sqrt": 11, "div": 12, "fma_aba": 13}
+               "min": 9, "max": 10, "sqrt": 11, "div": 12, "fma_aba": 13, "rcp": 14}
+
+    def kat_exhaustive(self, op: str) -> Tuple[int, int]:
+        """(number of binary32 inputs on which the kernels' 'rcp' / 'sqrt' differs from its definition, one such input's bits)."""
+        n, first = C.c_uint64(), C.c_uint32()
+        self._ck(self.lib.ptx_kat_exhaustive(self.h, {"rcp": 0, "sqrt": 1}[op], C.byref(n), C.byref(first)), "ptx_kat_exhaustive")
+        return int(n.value), int(first.value)
 
     def kat_math(self, op: str, a, b=None) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float32)

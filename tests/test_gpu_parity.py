@@ -81,16 +81,33 @@ def test_device_math_contract_bitwise(pt):
     y = rng.uniform(-40, 40, 200000).astype(np.float32)
     cases = {"sin": (x, None), "cos": (x, None), "asin": (x / 40, None), "acos": (x / 40, None), "log": (np.abs(x) + 1e-30, None),
              "log2": (np.abs(x), None), "exp2": (x * 4, None), "atan2": (x, y), "pow": (np.abs(x), y / 4), "min": (x, y),
-             "max": (x, y), "sqrt": (np.abs(x), None), "div": (x, y), "fma_aba": (x, y)}
+             "max": (x, y), "sqrt": (np.abs(x), None), "div": (x, y), "fma_aba": (x, y), "rcp": (x, None)}
     for op, (a, b) in cases.items():
         assert same_bits(pt.kat_math(op, a, b), orc.math_op(op, a, b)) == 0, op
-    # IEEE divide / sqrt are correctly rounded on the device
-    assert same_bits(pt.kat_math("div", x, y), (x.astype(np.float64) / y.astype(np.float64)).astype(np.float32)) == 0
+    # the reciprocal and the square root are correctly rounded; a / b is a * rcp(b)
+    r = (1.0 / x.astype(np.float64)).astype(np.float32)
+    assert same_bits(pt.kat_math("rcp", x), r) == 0
+    assert same_bits(pt.kat_math("div", y, x), y * r) == 0
     assert same_bits(pt.kat_math("sqrt", np.abs(x)), np.sqrt(np.abs(x).astype(np.float64)).astype(np.float32)) == 0
-    sp = np.array([0.0, -0.0, np.nan, 1.0, -0.0, np.inf, 1e-42], dtype=np.float32)
-    sq = np.array([-0.0, 0.0, 1.0, np.nan, -0.0, -np.inf, -1e-42], dtype=np.float32)
-    for op in ("min", "max", "div", "atan2", "pow", "log", "exp2"):
+    sp = np.array([0.0, -0.0, np.nan, 1.0, -0.0, np.inf, 1e-42, 1e-39, 3e38, -2e38, 2.0 ** 126, 1e-33, 5e-39], dtype=np.float32)
+    sq = np.array([-0.0, 0.0, 1.0, np.nan, -0.0, -np.inf, -1e-42, 2.0, 1e-39, 3.0, -(2.0 ** -126), 1e-36, 1.0], dtype=np.float32)
+    for op in ("min", "max", "div", "rcp", "sqrt", "atan2", "pow", "log", "exp2"):
         assert same_bits(pt.kat_math(op, sp, sq), orc.math_op(op, sp, sq)) == 0, op
+        assert same_bits(pt.kat_math(op, sq, sp), orc.math_op(op, sq, sp)) == 0, op
+
+
+def test_reciprocal_and_sqrt_sequences_match_their_definition_on_all_2_32_inputs(pt):
+    # the short device sequences against the definition, exhaustively (evaluated on the device)
+    assert pt.kat_exhaustive("rcp")[0] == 0
+    assert pt.kat_exhaustive("sqrt")[0] == 0
+    # and the definition itself against the CPU oracle on the subnormal / huge boundary cases
+    b = np.concatenate([np.arange(0, 1 << 12, dtype=np.uint32), np.uint32(0x00800000) + np.arange(-64, 64).astype(np.uint32),
+                        np.uint32(0x7E800000) + np.arange(-64, 64).astype(np.uint32), np.uint32(0x7F800000) - np.arange(0, 64).astype(np.uint32),
+                        np.uint32(0x0C800000) + np.arange(-64, 64).astype(np.uint32)])
+    b = np.concatenate([b, b | np.uint32(0x80000000)])
+    x = b.view(np.float32)
+    for op in ("rcp", "sqrt"):
+        assert same_bits(pt.kat_math(op, x), orc.math_op(op, x)) == 0, op
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "teapot", "all", "planet"])

@@ -170,3 +170,19 @@ def test_oracle_batched_equals_stepwise_and_tiled():
     for tile in [(0, 0, 17, 24), (17, 0, 23, 11), (17, 11, 23, 13)]:
         orc.render(sc, cam, 3, tile=tile, accum=acc)
     assert same_bits(acc, full["accum"]) == 0
+
+
+def test_division_contract_reciprocal_flushes_subnormals_and_is_correctly_rounded():
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-1e3, 1e3, 100000), 10.0 ** rng.uniform(-37, 37, 100000)]).astype(np.float32)
+    r = orc.math_op("rcp", x)
+    assert same_bits(r, (1.0 / x.astype(np.float64)).astype(np.float32)) == 0
+    y = rng.uniform(-50, 50, x.size).astype(np.float32)
+    with np.errstate(over="ignore"):
+        assert same_bits(orc.math_op("div", y, x), y * r) == 0  # a / b = a * rcp(b)
+    inf = np.float32(np.inf)
+    cases = [(0.0, inf), (-0.0, -inf), (1e-39, inf), (-1e-42, -inf), (1.17549435e-38, 2.0 ** 126), (2.0 ** 126, 2.0 ** -126),
+             (2.0 ** 127, 0.0), (-3e38, -0.0), (np.inf, 0.0), (-np.inf, -0.0)]
+    got = orc.math_op("rcp", np.array([c[0] for c in cases], dtype=np.float32))
+    assert same_bits(got, np.array([c[1] for c in cases], dtype=np.float32)) == 0
+    assert np.isnan(orc.math_op("rcp", np.array([np.nan], dtype=np.float32))[0])
