@@ -79,7 +79,8 @@ struct DScene {
     float root_min[3], root_max[3];
     int32_t sky_tex;          // texture id of the first textured skybox figure, or -1 (skybox.wgsl:9-20)
     float sky_color[3];       // its material base_color
-    uint32_t stack_entries;   // traversal stack slots per lane held in LDS (<= 31)
+    uint32_t stack_entries;   // traversal stack slots a lane can need (<= 31)
+    uint32_t lds_stack_entries;  // of those, slots held in LDS (all of them for the LDS-staged kernels)
     uint32_t npair;
     uint32_t has_fractals;    // any Mandelbulb / Julia figure in the BVH: selects the kernel variant with their marchers
     uint32_t lds_scene_bytes; // > 0: the scene records fit in LDS and the LDS-staged kernel is used

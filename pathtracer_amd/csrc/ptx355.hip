@@ -36,6 +36,7 @@ struct TraceParams {
     uint32_t* out_rgba8;
     uint32_t* primary_ids;
     float* m2;            // null unless moments are enabled
+    StackEntry* stack_spill;  // per-lane stack entries beyond the LDS part (null when none are needed)
     float* dbg_radiance;  // null unless capture is enabled
     uint32_t dbg_capacity;
     unsigned long long* stats;  // paths, bounces, shadow rays
@@ -69,10 +70,12 @@ template <bool LDS_SCENE, bool FRAC>
 PT_DEV void trace_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    StackEntry* st = lds_stack + (size_t)wave * P.sc.stack_entries * 64u + lane;
+    WalkStack st;
+    st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
+    st.glb = P.stack_spill ? P.stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
     DScene sc = P.sc;
     if (LDS_SCENE) {
-        char* base = (char*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.stack_entries * 64u) + (size_t)PTX_WAVES_PER_BLOCK * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u * 4u;
+        char* base = (char*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u) + (size_t)PTX_WAVES_PER_BLOCK * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u * 4u;
         uint32_t off = 0;
         auto stage = [&](const void* src, uint32_t bytes) -> void* {
             void* dst = base + off;
@@ -99,7 +102,7 @@ PT_DEV void trace_body(const TraceParams& P) {
 
     // Per-pixel state that is only touched when a path ends (running mean, M2, sample index, tallies)
     // lives in LDS, one lane-interleaved slot per field, so it does not occupy registers during traversal.
-    float* px_f = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.stack_entries * 64u) + (size_t)wave * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u + lane;
+    float* px_f = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u) + (size_t)wave * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u + lane;
     uint32_t* px_u = (uint32_t*)px_f;
     bool active = inside && P.n > 0u;
     {
@@ -284,11 +287,14 @@ extern "C" __global__ void ptx_kat_exhaustive_kernel(int op, uint32_t hi, unsign
 
 // Unit hook: one ray per lane through the same traversal code as the render kernels (WALK as they pick it).
 template <bool WALK>
-PT_DEV void kat_trace_body(const DScene& sc, const ptx_camera& cam, uint32_t n, const float* rays, const float* max_t, uint32_t* hit_id,
-                           float* hit_t, uint32_t* shadow) {
+PT_DEV void kat_trace_body(const DScene& sc, StackEntry* stack_spill, const ptx_camera& cam, uint32_t n, const float* rays, const float* max_t,
+                           uint32_t* hit_id, float* hit_t, uint32_t* shadow) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    StackEntry* st = lds_stack + (size_t)wave * sc.stack_entries * 64u + lane;
+    WalkStack st;
+    // the loop variant keeps the whole stack in LDS, the walk variant its first PT_LDS_STACK entries
+    st.lds = lds_stack + (size_t)wave * (WALK ? min(sc.stack_entries, PT_LDS_STACK) : sc.stack_entries) * 64u + lane;
+    st.glb = stack_spill ? stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray ray;
@@ -302,15 +308,15 @@ PT_DEV void kat_trace_body(const DScene& sc, const ptx_camera& cam, uint32_t n, 
     hit_t[i] = slot == PT_SLOT_NONE ? PT_MAX_T : t;
     if (shadow && max_t) shadow[i] = trace_shadow<true, WALK>(sc, ray, max_t[i], cam.fractal_march_steps, st) ? 1u : 0u;
 }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(const DScene sc, const ptx_camera cam, uint32_t n,
-                                                                            const float* rays, const float* max_t, uint32_t* hit_id,
-                                                                            float* hit_t, uint32_t* shadow) {
-    kat_trace_body<true>(sc, cam, n, rays, max_t, hit_id, hit_t, shadow);
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel(const DScene sc, StackEntry* stack_spill, const ptx_camera cam,
+                                                                            uint32_t n, const float* rays, const float* max_t,
+                                                                            uint32_t* hit_id, float* hit_t, uint32_t* shadow) {
+    kat_trace_body<true>(sc, stack_spill, cam, n, rays, max_t, hit_id, hit_t, shadow);
 }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel_loop(const DScene sc, const ptx_camera cam, uint32_t n,
                                                                                  const float* rays, const float* max_t, uint32_t* hit_id,
                                                                                  float* hit_t, uint32_t* shadow) {
-    kat_trace_body<false>(sc, cam, n, rays, max_t, hit_id, hit_t, shadow);
+    kat_trace_body<false>(sc, nullptr, cam, n, rays, max_t, hit_id, hit_t, shadow);
 }
 
 // ================================================================================================
@@ -336,6 +342,8 @@ struct ptx_ctx {
     float* dbg = nullptr;
     uint32_t dbg_cap = 0;
     unsigned long long* stats = nullptr;
+    StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
+    size_t spill_waves = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     std::vector<hipEvent_t> free_events;
@@ -358,6 +366,9 @@ int fail(ptx_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 void free_scene(ptx_ctx* c) {
+    if (c->spill) (void)hipFree(c->spill);
+    c->spill = nullptr;
+    c->spill_waves = 0;
     for (void* p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
     c->have_scene = false;
@@ -371,6 +382,21 @@ void free_frame(ptx_ctx* c) {
     if (c->dbg) (void)hipFree(c->dbg);
     c->accum = nullptr; c->out = nullptr; c->ids = nullptr; c->m2 = nullptr; c->dbg = nullptr;
     c->dbg_cap = 0;
+}
+
+// Makes room for the deep stack entries of `waves` waves (only scenes whose tree is deeper than PT_LDS_STACK
+// and that run the global-memory kernels need any).
+int ensure_spill(ptx_ctx* c, size_t waves, StackEntry** out) {
+    *out = nullptr;
+    if (c->sc.lds_scene_bytes > 0u || c->sc.stack_entries <= PT_LDS_STACK) return PTX_OK;
+    if (waves > c->spill_waves) {
+        if (c->spill) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->spill); c->spill = nullptr; c->spill_waves = 0; }
+        hipError_t e = hipMalloc((void**)&c->spill, waves * (31u - PT_LDS_STACK) * 64u * sizeof(StackEntry));
+        if (e != hipSuccess) return fail(c, PTX_ERR_OOM, "stack spill area: hipMalloc");
+        c->spill_waves = waves;
+    }
+    *out = c->spill;
+    return PTX_OK;
 }
 
 template <class T>
@@ -644,6 +670,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     memcpy(sc.sky_color, sky_color, 12);
     uint32_t entries = depth + 1;
     sc.stack_entries = entries > 31u ? 31u : entries;
+    sc.lds_stack_entries = sc.stack_entries;  // reduced below for the global-memory kernels
     sc.npair = (uint32_t)pairs.size();
     sc.has_fractals = 0u;
     for (const DPrim& g : dprims)
@@ -652,6 +679,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
         size_t bytes = dprims.size() * sizeof(DPrim) + dinf.size() * sizeof(DPrim) + pairs.size() * sizeof(DNodePair) +
                        shade.size() * sizeof(DShade) + dl.size() * sizeof(DLight) + negs.size() * sizeof(DNeg);
         sc.lds_scene_bytes = bytes <= PT_LDS_SCENE_MAX ? (uint32_t)bytes : 0u;
+        if (sc.lds_scene_bytes == 0u && sc.lds_stack_entries > PT_LDS_STACK) sc.lds_stack_entries = PT_LDS_STACK;
     }
     c->sc = sc;
     c->have_scene = true;
@@ -726,7 +754,8 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     P.m2 = c->moments ? c->m2 : nullptr;
     P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;
     P.stats = c->stats;
-    size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
+    size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.lds_stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
+    { int rc = ensure_spill(c, (size_t)P.n_blocks * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
     if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
     hipEvent_t e0, e1;
     int rc;
@@ -939,16 +968,19 @@ int ptx_kat_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t n, const float* ra
         rc = fail(c, PTX_ERR_HIP, "ptx_kat_trace: copy in");
     } else {
         size_t lds = (size_t)PTX_WAVES_PER_BLOCK * c->sc.stack_entries * 64u * sizeof(StackEntry);
+        const uint32_t blocks = (n + PTX_BLOCK - 1u) / PTX_BLOCK;
+        StackEntry* spill = nullptr;
         // Same traversal variant as ptx_trace picks for this scene (the records themselves stay in global memory here).
         if (c->sc.lds_scene_bytes > 0u)
-            hipLaunchKernelGGL(ptx_kat_trace_kernel_loop, dim3((n + PTX_BLOCK - 1u) / PTX_BLOCK), dim3(PTX_BLOCK), lds, c->stream, c->sc,
-                               *cam, n, dr, want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
-        else
-            hipLaunchKernelGGL(ptx_kat_trace_kernel, dim3((n + PTX_BLOCK - 1u) / PTX_BLOCK), dim3(PTX_BLOCK), lds, c->stream, c->sc, *cam, n,
-                               dr, want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
-        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(hit_id, did, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipLaunchKernelGGL(ptx_kat_trace_kernel_loop, dim3(blocks), dim3(PTX_BLOCK), lds, c->stream, c->sc, *cam, n, dr,
+                               want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
+        else if ((rc = ensure_spill(c, (size_t)blocks * PTX_WAVES_PER_BLOCK, &spill)) == PTX_OK)
+            hipLaunchKernelGGL(ptx_kat_trace_kernel, dim3(blocks), dim3(PTX_BLOCK), lds, c->stream, c->sc, spill, *cam, n, dr,
+                               want_shadow ? dm_ : nullptr, did, dt, want_shadow ? dsh : nullptr);
+        if (rc == PTX_OK &&
+            (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(hit_id, did, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(hit_t, dt, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            (want_shadow && hipMemcpy(shadow, dsh, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess))
+             (want_shadow && hipMemcpy(shadow, dsh, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)))
             rc = fail(c, PTX_ERR_HIP, "ptx_kat_trace: kernel or copy out");
     }
     if (dr) (void)hipFree(dr);

@@ -27,6 +27,22 @@ PT_DEV float intersect_aabb(V3 o, V3 inv_dir, const float* bmin, const float* bm
 // own box (bvh.wgsl:251-256): the value is a pure function of ray and box, so the comparison against
 // the current closest distance gives the same outcome.
 typedef uint2 StackEntry;
+// The walk variants (scenes read from global memory, possibly deep trees) keep only the first
+// PT_LDS_STACK entries of a lane's stack in LDS; deeper entries live in a per-lane global-memory area with
+// the same lane-interleaved layout.  Deep entries are rarely touched, and a 31-entry LDS stack (16 KB per
+// wave) would leave room for one wave per SIMD.  Push/pop semantics are unchanged.
+#define PT_LDS_STACK 8u
+struct WalkStack {
+    StackEntry* lds;  // entry e < PT_LDS_STACK of this lane at lds[e * 64]
+    StackEntry* glb;  // entry e >= PT_LDS_STACK at glb[(e - PT_LDS_STACK) * 64]
+};
+PT_DEV StackEntry stack_get(const WalkStack& w, int sp) {
+    return (uint32_t)sp < PT_LDS_STACK ? w.lds[sp * 64] : w.glb[(sp - (int)PT_LDS_STACK) * 64];
+}
+PT_DEV void stack_put(const WalkStack& w, int sp, StackEntry e) {
+    if ((uint32_t)sp < PT_LDS_STACK) w.lds[sp * 64] = e;
+    else w.glb[(sp - (int)PT_LDS_STACK) * 64] = e;
+}
 
 // Two loop shapes run the same per-lane sequence of box and primitive tests (the reference's):
 //   WALK = false (*_loop): one loop whose iteration is "pop, then either test the two child boxes or test every
@@ -110,7 +126,7 @@ PT_DEV void trace_positive_loop(const DScene& sc, const Ray& ray, V3 inv_dir, ui
 }
 
 template <bool FRAC>
-PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
+PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, const WalkStack& st,
                            float& t_best, uint32_t& slot_best, uint32_t& sub_best) {
     t_best = PT_MAX_T;
     slot_best = PT_SLOT_NONE;
@@ -128,7 +144,7 @@ PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, ui
                 if (!have) {
                     if (sp == 0) { finished = true; break; }
                     sp -= 1;
-                    StackEntry e = st[sp * 64];
+                    StackEntry e = stack_get(st, sp);
                     cur = e.x;
                     cur_t = __uint_as_float(e.y);
                 }
@@ -151,7 +167,7 @@ PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, ui
                     uint32_t far_e = left_near ? re : le, near_e = left_near ? le : re;
                     float far_t = left_near ? tr : tl, near_t = left_near ? tl : tr;
                     if (far_t < t_best && sp < 31) {
-                        st[sp * 64] = make_uint2(far_e, __float_as_uint(far_t));
+                        stack_put(st, sp, make_uint2(far_e, __float_as_uint(far_t)));
                         sp += 1;
                     }
                     if (near_t < t_best && sp < 31) {
@@ -188,10 +204,10 @@ PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, ui
 }
 
 template <bool FRAC, bool WALK>
-PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st,
+PT_DEV void trace_positive(const DScene& sc, const Ray& ray, V3 inv_dir, uint32_t march_steps, const WalkStack& st,
                            float& t_best, uint32_t& slot_best, uint32_t& sub_best) {
     if (WALK) trace_positive_walk<FRAC>(sc, ray, inv_dir, march_steps, st, t_best, slot_best, sub_best);
-    else trace_positive_loop<FRAC>(sc, ray, inv_dir, march_steps, st, t_best, slot_best, sub_best);
+    else trace_positive_loop<FRAC>(sc, ray, inv_dir, march_steps, st.lds, t_best, slot_best, sub_best);
 }
 
 // ---- CSG subtraction (bvh.wgsl:18-188) ----------------------------------------------------------------
@@ -287,7 +303,7 @@ PT_DEV const DPrim& slot_prim(const DScene& sc, uint32_t slot) {
 }
 // bvh.wgsl:143-188.  `ray` is updated to the ray that produced the final hit (its local distance t).
 template <bool FRAC, bool WALK>
-PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march_steps, StackEntry* st, float& t, uint32_t& slot,
+PT_DEV void trace_closest(const DScene& sc, Ray& ray, V3 inv_dir, uint32_t march_steps, const WalkStack& st, float& t, uint32_t& slot,
                           uint32_t& sub) {
     trace_positive<FRAC, WALK>(sc, ray, inv_dir, march_steps, st, t, slot, sub);
     if (sc.nneg > 0u && slot != PT_SLOT_NONE) {
@@ -363,7 +379,7 @@ PT_DEV bool trace_shadow_loop(const DScene& sc, const Ray& ray, float max_t, uin
 }
 
 template <bool FRAC>
-PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
+PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, const WalkStack& st) {
     V3 inv_dir = vrcp(ray.d);
     const float t_lim = max_t - PT_EPS;
     bool occluded = false;
@@ -380,7 +396,7 @@ PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uin
                 if (!have) {
                     if (sp == 0) { finished = true; break; }
                     sp -= 1;
-                    StackEntry e = st[sp * 64];
+                    StackEntry e = stack_get(st, sp);
                     cur = e.x;
                     cur_t = __uint_as_float(e.y);
                 }
@@ -397,7 +413,7 @@ PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uin
                     float tl = intersect_aabb(ray.o, inv_dir, nd.lmin, nd.lmax);
                     float tr = intersect_aabb(ray.o, inv_dir, nd.rmin, nd.rmax);
                     if (sp < 31) {
-                        st[sp * 64] = make_uint2(nd.lref | (nd.lcnt << PT_REF_BITS), __float_as_uint(tl));
+                        stack_put(st, sp, make_uint2(nd.lref | (nd.lcnt << PT_REF_BITS), __float_as_uint(tl)));
                         sp += 1;
                     }
                     if (sp < 31) {
@@ -429,8 +445,8 @@ PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uin
 }
 
 template <bool FRAC, bool WALK>
-PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, StackEntry* st) {
-    return WALK ? trace_shadow_walk<FRAC>(sc, ray, max_t, march_steps, st) : trace_shadow_loop<FRAC>(sc, ray, max_t, march_steps, st);
+PT_DEV bool trace_shadow(const DScene& sc, const Ray& ray, float max_t, uint32_t march_steps, const WalkStack& st) {
+    return WALK ? trace_shadow_walk<FRAC>(sc, ray, max_t, march_steps, st) : trace_shadow_loop<FRAC>(sc, ray, max_t, march_steps, st.lds);
 }
 
 // ---- textures.wgsl:13-29 ---------------------------------------------------------------------------
@@ -623,7 +639,7 @@ struct PathState {
 };
 #define PT_PARK_FIELDS 23u  // per-lane LDS slots for values parked across the occlusion query
 template <bool FRAC, bool WALK>
-PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, StackEntry* st, float* park, uint32_t& hit_fig,
+PT_DEV bool bounce_step(const DScene& sc, const ptx_camera& cam, PathState& ps, const WalkStack& st, float* park, uint32_t& hit_fig,
                         uint32_t& n_shadow) {
     PT_SITE(0);
     Ray ray = ps.ray;

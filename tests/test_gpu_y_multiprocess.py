@@ -22,6 +22,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)  # a stuck rank reports where, and does not outlive the test
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -65,10 +67,15 @@ def test_two_ranks_sample_split_and_tiles():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    n, merged, merged_out, tiles, tiles_out = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        n, merged, merged_out, tiles, tiles_out = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     assert n == 12
     sc = host.Scene.from_fixture(fixture("cornell_box")).build()
     pt = PathTracer(0)

@@ -26,9 +26,13 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box"
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 640
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 360
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+quads = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # > 0: add the synthetic height-field mesh (2 * quads^2 triangles)
 pt = PathTracer(0)
 lib = pt.lib
-sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
+sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz"))
+if quads:
+    sc.append_heightfield(quads)
+sc.build(decode_textures=False)
 cam = sc.camera(w, h)
 sc.upload_to(pt)
 pt.resize(w, h)
@@ -43,7 +47,10 @@ fn(buf.ctypes.data, 96)
 ms, _ = pt.kernel_time()
 st = pt.stats()
 wb = float(buf[0])
-print(f"{name} {w}x{h} n={n} kernel={pt.kernel_name()} lane-bounces/wave-bounce={st['bounces'] / wb:.1f}")
+print(f"{name} {w}x{h} n={n} quads={quads} kernel={pt.kernel_name()} {ms:.1f} ms lane-bounces/wave-bounce={st['bounces'] / wb:.1f} "
+      f"paths={st['paths']} bounces={st['bounces']} shadow_rays={st['shadow_rays']}")
+pairs, tris = float(buf[2 * 2 + 1]), float(buf[2 * 17 + 1])
+print(f"BVH records fetched: {pairs:.0f} node pairs + {tris:.0f} triangles = {(pairs + tris) * 64 / 1e9:.2f} GB (64 B each)")
 print(f"{'site':22s} {'execs/wave-bounce':>18s} {'mean lanes':>11s} {'lane-execs/lane-bounce':>23s}")
 for i in range(96):
     c, l = float(buf[2 * i]), float(buf[2 * i + 1])
