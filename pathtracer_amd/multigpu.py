@@ -75,7 +75,12 @@ def assemble_tiles(tracer, dist, device, cam=None):
     tracer.sync()
     n = tracer.width * tracer.height
     acc = device_tensor(tracer.device_accum_ptr(), (n * 4,), torch.float32, device)
-    dist.all_reduce(acc)
+    if _host_staged(dist, device):
+        host = acc.cpu()
+        dist.all_reduce(host)
+        acc.copy_(host)
+    else:
+        dist.all_reduce(acc)
     torch.cuda.synchronize(device)
     if cam is not None:
         tracer.tonemap(0, n, cam)
@@ -108,9 +113,13 @@ def merge_sample_split(tracer, dist, device, counts: List[int], cam):
         n_a += counts[r]
     tracer.sync()
     # merged slices back to everyone
-    gathered = [torch.empty((c, 4), dtype=torch.float32, device=device) for _, c in slices]
-    dist.all_gather(gathered, acc[mine[0]:mine[0] + mine[1]].contiguous()) if len({c for _, c in slices}) == 1 else \
-        _all_gather_uneven(dist, gathered, acc[mine[0]:mine[0] + mine[1]].contiguous(), slices, device)
+    xdev = torch.device("cpu") if _host_staged(dist, device) else device
+    gathered = [torch.empty((c, 4), dtype=torch.float32, device=xdev) for _, c in slices]
+    merged = acc[mine[0]:mine[0] + mine[1]].contiguous().to(xdev)
+    if len({c for _, c in slices}) == 1:
+        dist.all_gather(gathered, merged)
+    else:
+        _all_gather_uneven(dist, gathered, merged, slices)
     for (f, c), g in zip(slices, gathered):
         acc[f:f + c].copy_(g)
     torch.cuda.synchronize(device)
@@ -119,22 +128,32 @@ def merge_sample_split(tracer, dist, device, counts: List[int], cam):
     return n_a
 
 
+def _host_staged(dist, device) -> bool:
+    """gloo (the test backend) moves device buffers through host copies made here: its own handling of device
+    tensors stalls now and then when two ranks share one GPU.  RCCL works on the device buffers directly."""
+    import torch
+    return dist.get_backend() != "nccl" and torch.device(device).type != "cpu"
+
+
 def _exchange_slices(dist, buf, slices, rank, world, width, device):
     """Every rank sends slice j of `buf` to rank j and receives slice `rank` from everyone.  RCCL: one
     all-to-all (all peer links busy at once); gloo (tests): one gather per destination."""
     import torch
     mine = slices[rank]
-    recv = [torch.empty((mine[1], width), dtype=torch.float32, device=device) for _ in range(world)]
-    send = [buf[f:f + c].contiguous() for f, c in slices]
     if dist.get_backend() == "nccl":
+        recv = [torch.empty((mine[1], width), dtype=torch.float32, device=device) for _ in range(world)]
+        send = [buf[f:f + c].contiguous() for f, c in slices]
         dist.all_to_all(recv, send)
-    else:
-        for dst in range(world):
-            dist.gather(send[dst], recv if rank == dst else None, dst=dst)
-    return recv
+        return recv
+    xdev = torch.device("cpu") if _host_staged(dist, device) else device
+    recv = [torch.empty((mine[1], width), dtype=torch.float32, device=xdev) for _ in range(world)]
+    send = [buf[f:f + c].contiguous().to(xdev) for f, c in slices]
+    for dst in range(world):
+        dist.gather(send[dst], recv if rank == dst else None, dst=dst)
+    return [r.to(device) for r in recv]
 
 
-def _all_gather_uneven(dist, out_list, mine, slices, device):
+def _all_gather_uneven(dist, out_list, mine, slices):
     for r, (_, c) in enumerate(slices):
         buf = mine if r == dist.get_rank() else out_list[r]
         dist.broadcast(buf, src=r)
