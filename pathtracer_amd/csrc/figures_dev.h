@@ -752,6 +752,112 @@ PT_DEV void finish_fractal(const Ray& ray, const DPrim& g, float t, HitFull* h) 
     h->uv.y = 0.0f;
 }
 
+// ---- the ray marchers as resumable steps ------------------------------------------------------------------
+// The scheduled kernels (sched_dev.h) run a marcher one loop iteration at a time, so that lanes that march can
+// be served together however long each of them marches.  march_begin_* is the code before the loop (false =
+// the ray misses the bounding sphere), march_step_* one iteration: MARCH_GO = iterate again, MARCH_HIT = hit at
+// m.t, MARCH_MISS.  The arithmetic, and so every result, is that of march_torus / march_mebius / march_fractal.
+struct MarchState { float t, prev_d, max_t; uint32_t i; };
+enum : int { MARCH_GO = 0, MARCH_HIT = 1, MARCH_MISS = 2 };
+PT_DEV bool march_begin_torus(const Ray& ray, const DPrim& g, MarchState& m) {
+    float major_r = g.p[3], minor_r = g.p[4];
+    float bound_r = major_r + minor_r;
+    V3 oc = ray.o - v3p(g.p);
+    float b = dot(oc, ray.d);
+    float br = bound_r + minor_r;
+    float cc = dot(oc, oc) - br * br;
+    float disc = dm::fma_(b, b, -cc);
+    if (disc < 0.0f) return false;
+    float sq = dm::sqrt_(dm::fmax_(disc, 0.0f));
+    m.t = dm::fmax_(-b - sq, PT_EPS);
+    m.max_t = dm::fmin_(-b + sq, PT_MAX_T);
+    m.prev_d = 0.0f;
+    m.i = 0u;
+    return true;
+}
+PT_DEV int march_step_torus(const Ray& ray, const DPrim& g, MarchState& m) {
+    const float omega = 1.4f;
+    float major_r = g.p[3], minor_r = g.p[4];
+    V3 pos = v3p(g.p);
+    V3 p = madd(ray.o, ray.d, m.t) - pos;
+    float d = sdf_torus(p, major_r, minor_r);
+    if (d < 0.0f && m.prev_d > 0.0f) {
+        m.t -= m.prev_d * (omega - 1.0f);
+        V3 p2 = madd(ray.o, ray.d, m.t) - pos;
+        float d2 = sdf_torus(p2, major_r, minor_r);
+        m.t += d2;
+        m.prev_d = d2;
+    } else {
+        if (dm::abs_(d) < PT_EPS * m.t) return MARCH_HIT;
+        m.t += d * omega;
+        m.prev_d = d;
+        if (m.t > m.max_t) return MARCH_MISS;
+    }
+    m.i += 1u;
+    return m.i < 128u ? MARCH_GO : MARCH_MISS;
+}
+PT_DEV bool march_begin_mebius(const Ray& ray, const DPrim& g, MarchState& m) {
+    float R = g.p[3];
+    V3 oc = ray.o - v3p(g.p);
+    float b = dot(oc, ray.d);
+    float bound_r = R * 1.5f;
+    float cc = dot(oc, oc) - bound_r * bound_r;
+    float disc = dm::fma_(b, b, -cc);
+    if (disc < 0.0f) return false;
+    float sq = dm::sqrt_(disc);
+    m.t = dm::fmax_(-b - sq, PT_EPS);
+    m.max_t = -b + sq;
+    m.prev_d = 0.0f;
+    m.i = 0u;
+    return true;
+}
+PT_DEV int march_step_mebius(const Ray& ray, const DPrim& g, MarchState& m) {
+    V3 p = madd(ray.o, ray.d, m.t) - v3p(g.p);
+    float d = sdf_mebius(p, g.p[3]);
+    if (dm::abs_(d) < PT_EPS * m.t * 0.5f) return MARCH_HIT;
+    m.t += d;
+    if (m.t > m.max_t) return MARCH_MISS;
+    m.i += 1u;
+    return m.i < 256u ? MARCH_GO : MARCH_MISS;
+}
+PT_DEV bool march_begin_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, MarchState& m) {
+    float radius = g.p[3];
+    V3 oc = ray.o - v3p(g.p);
+    float b = dot(oc, ray.d);
+    float bound_r = radius * 1.5f;
+    float cs = dot(oc, oc) - bound_r * bound_r;
+    float disc = dm::fma_(b, b, -cs);
+    if (disc < 0.0f) return false;
+    float sq = dm::sqrt_(disc);
+    m.t = dm::fmax_(-b - sq, PT_EPS);
+    m.max_t = -b + sq;
+    m.prev_d = 0.0f;
+    m.i = 0u;
+    return march_steps > 0u;
+}
+PT_DEV int march_step_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, MarchState& m) {
+    const float omega = 1.3f;
+    V3 pos = v3p(g.p);
+    float radius = g.p[3];
+    const float inv_radius = dm::rcp_(radius);
+    V3 p = madd(ray.o, ray.d, m.t) - pos;
+    float d = sdf_eval<true>(g, p * inv_radius) * radius;
+    if (d < 0.0f && m.prev_d > 0.0f) {
+        m.t -= m.prev_d * (omega - 1.0f);
+        V3 p2 = madd(ray.o, ray.d, m.t) - pos;
+        float d2 = sdf_eval<true>(g, p2 * inv_radius) * radius;
+        m.t += d2;
+        m.prev_d = d2;
+    } else {
+        if (dm::abs_(d) < PT_EPS * m.t * 0.5f) return MARCH_HIT;
+        m.t += d * omega;
+        m.prev_d = d;
+        if (m.t > m.max_t) return MARCH_MISS;
+    }
+    m.i += 1u;
+    return m.i < march_steps ? MARCH_GO : MARCH_MISS;
+}
+
 // Candidate test: hit distance only (figures/dispatch.wgsl:22-89).
 // `sub` receives the winning face of a pyramid / tetrahedron (0 otherwise) for resolve_hit.
 template <bool FRAC>
@@ -774,6 +880,27 @@ PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t mar
         case FIG_PARABOLOID: return isect_paraboloid<false>(ray, g, t, nullptr, false);
         case FIG_HYPERBOLOID: return isect_hyperboloid<false>(ray, g, t, nullptr, false);
         case FIG_MEBIUS: return march_mebius(ray, g, t);
+        case FIG_PYRAMID: return isect_pyramid<false>(ray, g, t, nullptr, sub);
+        case FIG_TETRAHEDRON: return isect_tetrahedron<false>(ray, g, t, nullptr, sub);
+        default: return false;
+    }
+}
+// The closed-form types only (the scheduled kernels run the marchers as separate steps).
+PT_DEV bool intersect_closed(const Ray& ray, V3 inv_dir, const DPrim& g, float& t, uint32_t& sub) {
+    sub = 0u;
+    PT_SITE_TYPED(10, g.type);
+    switch (g.type) {
+        case FIG_SPHERE: return isect_sphere<false>(ray, g, t, nullptr, false);
+        case FIG_PLANE: return isect_plane<false>(ray, g, t, nullptr, false);
+        case FIG_CUBE: return isect_cube<false>(ray, inv_dir, g, t, nullptr);
+        case FIG_CYLINDER: return isect_cylinder<false>(ray, g, t, nullptr, false);
+        case FIG_CONE: return isect_cone<false>(ray, g, t, nullptr, false);
+        case FIG_DISC: return isect_disc<false>(ray, g, t, nullptr);
+        case FIG_TRIANGLE: return isect_triangle<false>(ray, g, t, nullptr, false, nullptr);
+        case FIG_SKYBOX: return isect_skybox<false>(ray, g, t, nullptr, false);
+        case FIG_ELLIPSOID: return isect_ellipsoid<false>(ray, g, t, nullptr, false);
+        case FIG_PARABOLOID: return isect_paraboloid<false>(ray, g, t, nullptr, false);
+        case FIG_HYPERBOLOID: return isect_hyperboloid<false>(ray, g, t, nullptr, false);
         case FIG_PYRAMID: return isect_pyramid<false>(ray, g, t, nullptr, sub);
         case FIG_TETRAHEDRON: return isect_tetrahedron<false>(ray, g, t, nullptr, sub);
         default: return false;

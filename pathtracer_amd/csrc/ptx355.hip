@@ -13,10 +13,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
-#include "trace_dev.h"
+#include "sched_dev.h"
 
 #define PTX_BLOCK 256
 #define PTX_WAVES_PER_BLOCK 4
@@ -25,22 +26,6 @@
 #define PTX_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
 
-struct TraceParams {
-    DScene sc;
-    ptx_camera cam;
-    uint32_t first_frame, first_sample, n;
-    uint32_t tile_x0, tile_y0, tile_w, tile_h;
-    uint32_t blocks_x, n_blocks;        // 16x16-pixel blocks across the tile; blocks this launch runs
-    uint32_t part_rank, part_world;      // this launch owns tile blocks part_rank, part_rank + part_world, ...
-    float4* accum;
-    uint32_t* out_rgba8;
-    uint32_t* primary_ids;
-    float* m2;            // null unless moments are enabled
-    StackEntry* stack_spill;  // per-lane stack entries beyond the LDS part (null when none are needed)
-    float* dbg_radiance;  // null unless capture is enabled
-    uint32_t dbg_capacity;
-    unsigned long long* stats;  // paths, bounces, shadow rays
-};
 
 // Bijective block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so give the
 // blocks of one XCD a contiguous range of logical tile indices.
@@ -73,6 +58,7 @@ PT_DEV void trace_body(const TraceParams& P) {
     WalkStack st;
     st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
     st.glb = P.stack_spill ? P.stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
+    st.nl = P.sc.lds_stack_entries;
     DScene sc = P.sc;
     if (LDS_SCENE) {
         char* base = (char*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u) + (size_t)PTX_WAVES_PER_BLOCK * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u * 4u;
@@ -204,12 +190,124 @@ PT_DEV void trace_body(const TraceParams& P) {
     }
 }
 
+// The wave-scheduled kernel body (sched_dev.h): same buffers and results as trace_body; the grid is sized to
+// the GPU, not to the frame, and lanes claim pixels as they go.
+#ifndef SCH_WALK_SHARE
+#define SCH_WALK_SHARE 4u   // WALK is served when its lanes are at least 1/4 of the live lanes
+#endif
+#ifndef SCH_POST_SHARE
+#define SCH_POST_SHARE 2u   // POST: 1/2
+#endif
+#ifndef SCH_MARCH_SHARE
+#define SCH_MARCH_SHARE 4u  // a marcher: 1/4
+#endif
+static_assert(SC_PIXEL_FIELDS + SC_PARK_FIELDS == PT_PIXEL_FIELDS + PT_PARK_FIELDS, "both kernel families share one LDS budget");
+template <bool LDS_SCENE, bool FRAC>
+PT_DEV void sched_body(const TraceParams& P) {
+    extern __shared__ StackEntry lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    WalkStack st;
+    st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
+    st.glb = P.stack_spill ? P.stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
+    st.nl = P.sc.lds_stack_entries;
+    float* fields = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u);
+    DScene sc = P.sc;
+    if (LDS_SCENE) {
+        char* base = (char*)(fields + (size_t)PTX_WAVES_PER_BLOCK * (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u);
+        uint32_t off = 0;
+        auto stage = [&](const void* src, uint32_t bytes) -> void* {
+            void* dst = base + off;
+            copy_to_lds(dst, src, bytes);
+            off += bytes;
+            return dst;
+        };
+        sc.prims = (const DPrim*)stage(P.sc.prims, P.sc.nprim * (uint32_t)sizeof(DPrim));
+        sc.inf = (const DPrim*)stage(P.sc.inf, P.sc.ninf * (uint32_t)sizeof(DPrim));
+        sc.pairs = (const DNodePair*)stage(P.sc.pairs, P.sc.npair * (uint32_t)sizeof(DNodePair));
+        sc.shade = (const DShade*)stage(P.sc.shade, P.sc.nfig * (uint32_t)sizeof(DShade));
+        sc.lights = (const DLight*)stage(P.sc.lights, P.sc.nlight * (uint32_t)sizeof(DLight));
+        sc.negs = (const DNeg*)stage(P.sc.negs, P.sc.nneg * (uint32_t)sizeof(DNeg));
+        __syncthreads();
+    }
+    float* px_f = fields + (size_t)wave * (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u + lane;
+    uint32_t* px_u = (uint32_t*)px_f;
+    float* park = px_f + SC_PIXEL_FIELDS * 64u;
+    px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
+    px_u[6 * 64] = 0u;  // samples of the current pixel finished
+    px_u[7 * 64] = 0u;  // path-bounces, all pixels of this lane
+    uint32_t n_shadow = 0;
+    Trav tv;
+    tv.ray.o = v3(0.0f, 0.0f, 0.0f);
+    tv.ray.d = v3(0.0f, 0.0f, 1.0f);
+    tv.inv_dir = v3(0.0f, 0.0f, 0.0f);
+    tv.bound = 0.0f; tv.slot = PT_SLOT_NONE; tv.sub = 0u; tv.sp = 0; tv.cur = 0u; tv.cur_t = 0.0f; tv.pi = 0u; tv.pend = 0u;
+    tv.have = false; tv.shadow = false;
+    tv.m.t = 0.0f; tv.m.prev_d = 0.0f; tv.m.max_t = 0.0f; tv.m.i = 0u;
+    uint32_t S = LS_IDLE;
+    uint32_t job = blockIdx.x * PTX_BLOCK + threadIdx.x;  // the first job of every lane; the counter starts behind them
+    if (P.n > 0u) {
+        PixelJob J;
+        if (claim_pixel(P, job, true, px_f, J)) {
+            Ray r0;
+            r0.o = v3(0.0f, 0.0f, 0.0f);
+            r0.d = v3(0.0f, 0.0f, 1.0f);
+            S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u);
+        }
+    }
+    // The scheduler.  A state is served when enough of the wave's live lanes wait in it: WALK steps are cheap
+    // and feed the other states, so they run from a quarter of the live lanes; the long POST step waits for
+    // half; a marcher for a quarter and then keeps stepping while three quarters of its lanes are still
+    // marching.  When no state reaches its share the fullest one is served, so every round makes progress.
+    for (;;) {
+        uint32_t pop[LS_COUNT];
+        uint32_t live = 0u, fullest = LS_IDLE, fullest_n = 0u, march = LS_IDLE, march_n = 0u;
+#pragma unroll
+        for (uint32_t s = LS_WALK; s < (uint32_t)LS_COUNT; s++) {
+            pop[s] = (!FRAC && s >= (uint32_t)LS_MANDEL) ? 0u : (uint32_t)__popcll(__ballot(S == s));
+            live += pop[s];
+            if (pop[s] > fullest_n) { fullest_n = pop[s]; fullest = s; }
+            if (s >= (uint32_t)LS_TORUS && pop[s] > march_n) { march_n = pop[s]; march = s; }
+        }
+        if (live == 0u) break;
+        uint32_t pick = fullest;
+        if (pop[LS_WALK] * SCH_WALK_SHARE >= live) pick = LS_WALK;
+        else if (pop[LS_POST] * SCH_POST_SHARE >= live) pick = LS_POST;
+        else if (march_n * SCH_MARCH_SHARE >= live) pick = march;
+        if (pick == LS_WALK) {
+            for (;;) {
+                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps);
+                const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
+                if (w == 0u || w * SCH_WALK_SHARE < live) break;
+            }
+        } else if (pick == LS_POST) {
+            if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, px_f, job, n_shadow);
+        } else {
+            const uint32_t n0 = pop[pick];
+            for (;;) {
+                if (S == pick) S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps);
+                const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
+                if (m == 0u || m * 4u < n0 * 3u) break;
+            }
+        }
+    }
+    const uint32_t n_bounce = px_u[7 * 64];
+    uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
+    if (lane == 0u && P.stats) {  // paths were added pixel by pixel
+        atomicAdd(&P.stats[1], (unsigned long long)sb);
+        atomicAdd(&P.stats[2], (unsigned long long)ss);
+    }
+}
+
 // Four variants: scene records in global memory or staged in LDS; with or without the fractal marchers.
 // Without them the kernel fits 128 VGPRs (4 waves per SIMD); with them 3 waves.
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_sched_kernel(const TraceParams P) { sched_body<false, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_sched_kernel_lds(const TraceParams P) { sched_body<true, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_frac(const TraceParams P) { sched_body<false, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_lds_frac(const TraceParams P) { sched_body<true, true>(P); }
 
 // Chan's parallel update of (mean, M2) with another partial result, then re-tonemap.
 extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* out_rgba8, uint32_t first, uint32_t n_pixels,
@@ -295,6 +393,7 @@ PT_DEV void kat_trace_body(const DScene& sc, StackEntry* stack_spill, const ptx_
     // the loop variant keeps the whole stack in LDS, the walk variant its first PT_LDS_STACK entries
     st.lds = lds_stack + (size_t)wave * (WALK ? min(sc.stack_entries, PT_LDS_STACK) : sc.stack_entries) * 64u + lane;
     st.glb = stack_spill ? stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
+    st.nl = WALK ? min(sc.stack_entries, PT_LDS_STACK) : sc.stack_entries;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray ray;
@@ -342,6 +441,8 @@ struct ptx_ctx {
     float* dbg = nullptr;
     uint32_t dbg_cap = 0;
     unsigned long long* stats = nullptr;
+    bool sched = false;           // the uploaded scene runs the wave-scheduled kernels
+    uint32_t n_cu = 0;            // compute units of the device
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
     size_t spill_waves = 0;
     // timing
@@ -480,6 +581,9 @@ int ptx_create(int device, ptx_ctx** out) {
         delete c;
         return PTX_ERR_HIP;
     }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    c->n_cu = (uint32_t)cus;
     *out = c;
     return PTX_OK;
 }
@@ -498,6 +602,18 @@ void ptx_destroy(ptx_ctx* c) {
 }
 
 const char* ptx_last_error(const ptx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// Which kernel family runs a scene.  The wave-scheduled kernels win wherever lanes need very unequal numbers of
+// steps: trees read from global memory (meshes) and the long ray marchers (Moebius, Mandelbulb, Julia); small
+// closed-form scenes (the Cornell box, torus included) run faster in lockstep.  PTX355_SCHED=0/1 in the
+// environment overrides the rule (measurement runs).
+static bool pick_sched(const DScene& sc, const std::vector<DPrim>& prims) {
+    if (const char* e = getenv("PTX355_SCHED")) return e[0] == '1';
+    if (sc.lds_scene_bytes == 0u || sc.has_fractals != 0u) return true;
+    for (const DPrim& g : prims)
+        if (g.type == FIG_MEBIUS) return true;
+    return false;
+}
 
 // The division contract's reciprocal (dmath_dev.h) for values precomputed on the host.
 static float host_rcp(float y) {
@@ -683,6 +799,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     }
     c->sc = sc;
     c->have_scene = true;
+    c->sched = pick_sched(sc, dprims);
     return PTX_OK;
 }
 
@@ -755,20 +872,26 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;
     P.stats = c->stats;
     size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.lds_stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
-    { int rc = ensure_spill(c, (size_t)P.n_blocks * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
+    // The scheduled kernels run a grid sized to the GPU (4 workgroups per compute unit fit at most) whose lanes
+    // claim pixels from a counter that starts behind the grid's own first jobs.
+    const uint32_t grid = c->sched ? (P.n_blocks < c->n_cu * 4u ? P.n_blocks : c->n_cu * 4u) : P.n_blocks;
+    { int rc = ensure_spill(c, (size_t)grid * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
+    if (c->sched) {
+        P.job_counter = (uint32_t*)&c->stats[15];
+        P.total_jobs = P.n_blocks * 256u;
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
+    }
     if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
     hipEvent_t e0, e1;
     int rc;
     if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     const bool frac = c->sc.has_fractals != 0u;
-    if (c->sc.lds_scene_bytes > 0u) {
-        if (frac) hipLaunchKernelGGL(ptx_trace_kernel_lds_frac, dim3(P.n_blocks), dim3(PTX_BLOCK), lds + c->sc.lds_scene_bytes, c->stream, P);
-        else hipLaunchKernelGGL(ptx_trace_kernel_lds, dim3(P.n_blocks), dim3(PTX_BLOCK), lds + c->sc.lds_scene_bytes, c->stream, P);
-    } else {
-        if (frac) hipLaunchKernelGGL(ptx_trace_kernel_frac, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
-        else hipLaunchKernelGGL(ptx_trace_kernel, dim3(P.n_blocks), dim3(PTX_BLOCK), lds, c->stream, P);
-    }
+    const size_t lds_all = lds + c->sc.lds_scene_bytes;  // lds_scene_bytes is 0 for the global-memory kernels
+    void (*kernel)(const TraceParams) =
+        c->sched ? (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_sched_kernel_lds_frac : ptx_sched_kernel_lds) : (frac ? ptx_sched_kernel_frac : ptx_sched_kernel))
+                 : (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_trace_kernel_lds_frac : ptx_trace_kernel_lds) : (frac ? ptx_trace_kernel_frac : ptx_trace_kernel));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->pending.push_back({e0, e1});
@@ -875,6 +998,7 @@ extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
 const char* ptx_trace_kernel_name(const ptx_ctx* c) {
     if (!c || !c->have_scene) return "";
     const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
+    if (c->sched) return lds ? (frac ? "ptx_sched_kernel_lds_frac" : "ptx_sched_kernel_lds") : (frac ? "ptx_sched_kernel_frac" : "ptx_sched_kernel");
     return lds ? (frac ? "ptx_trace_kernel_lds_frac" : "ptx_trace_kernel_lds") : (frac ? "ptx_trace_kernel_frac" : "ptx_trace_kernel");
 }
 

@@ -1,0 +1,472 @@
+// Wave-scheduled form of the path state machine.
+//
+// In trace_body (ptx355.hip) every lane of a wave runs the same phase at the same time: closest-hit
+// traversal, shading, occlusion traversal, shading.  A phase lasts as long as its slowest lane, so a wave
+// whose lanes need 5, 40 and 300 traversal steps (a mesh) or 0, 10 and 256 marching steps (a fractal) runs
+// most instructions for a handful of lanes.  Here each lane carries its own state,
+//     WALK   walking the BVH (at an inner node, or at a closed-form leaf primitive),
+//     MARCH  inside one of the ray marchers (torus, Moebius, Mandelbulb, Julia), one loop iteration at a time,
+//     POST   traversal finished: plane list, CSG retry, shading, next ray or next sample,
+// and the wave repeatedly picks, by ballot, the state most of its lanes are in and runs ONE step of it for
+// those lanes.  Lanes that finish a long phase early move on and come back with new rays, so the lanes pile up
+// in front of the expensive steps instead of idling behind the slowest of them.  The arithmetic a lane performs,
+// and the order it performs it in, are exactly those of trace_body (same functions, same expression trees), so
+// results are bit-identical; only the interleaving between lanes changes.
+//
+// Reference: the per-invocation control flow of src/shaders/wgsl/path_trace.wgsl:56-183 and bvh.wgsl:143-362.
+#pragma once
+#include "trace_dev.h"
+
+// Kernel arguments of the trace kernels (both families).
+struct TraceParams {
+    DScene sc;
+    ptx_camera cam;
+    uint32_t first_frame, first_sample, n;
+    uint32_t tile_x0, tile_y0, tile_w, tile_h;
+    uint32_t blocks_x, n_blocks;        // 16x16-pixel blocks across the tile; blocks this launch runs
+    uint32_t part_rank, part_world;      // this launch owns tile blocks part_rank, part_rank + part_world, ...
+    float4* accum;
+    uint32_t* out_rgba8;
+    uint32_t* primary_ids;
+    float* m2;            // null unless moments are enabled
+    StackEntry* stack_spill;  // per-lane stack entries beyond the LDS part (null when none are needed)
+    float* dbg_radiance;  // null unless capture is enabled
+    uint32_t dbg_capacity;
+    unsigned long long* stats;  // paths, bounces, shadow rays
+    uint32_t* job_counter;  // scheduled kernels: next unclaimed pixel job
+    uint32_t total_jobs;    // n_blocks * 256
+};
+
+enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS = 4, LS_MANDEL = 5, LS_JULIA = 6, LS_COUNT = 7 };
+
+// Per-lane LDS slots (lane-interleaved: slot f of this lane at base[f * 64]).
+#define SC_PIXEL_FIELDS 8u   // mean xyz, M2 xyz, samples finished, path-bounce tally
+#define SC_PARK_FIELDS 24u   // below
+enum : uint32_t {
+    PK_HPOS = 0, PK_N = 3, PK_BASE = 6, PK_FIG = 9, PK_CONTRIB = 10,  // inputs of the BSDF step, parked across the occlusion query
+    PK_THR = 13, PK_RAD = 16, PK_RNG = 19, PK_MISC = 20,              // path state; MISC = bounce | csg attempt << 24 | lit << 31
+    PK_WO = 21
+};
+
+struct Trav {
+    Ray ray;
+    V3 inv_dir;
+    float bound;          // closest: nearest hit so far; occlusion: distance to the light
+    uint32_t slot, sub;   // closest: best primitive slot / face; occlusion: slot != PT_SLOT_NONE means occluded
+    int sp;
+    uint32_t cur;
+    float cur_t;
+    uint32_t pi, pend;    // primitives [pi, pend) of the current leaf are still to be tested
+    bool have, shadow;
+    MarchState m;
+};
+
+// Starts a traversal of tv.ray (inv_dir set by the caller).  bvh.wgsl:236-249 / 308-322.
+PT_DEV void trav_begin(const DScene& sc, Trav& tv, bool shadow, float bound) {
+    tv.shadow = shadow;
+    tv.bound = bound;
+    tv.slot = PT_SLOT_NONE;
+    tv.sub = 0u;
+    tv.sp = 0;
+    tv.cur = sc.root_ref;
+    tv.cur_t = sc.nprim > 0u ? intersect_aabb(tv.ray.o, tv.inv_dir, sc.root_min, sc.root_max) : PT_MAX_T;
+    tv.have = sc.nprim > 0u;
+    tv.pi = 0u;
+    tv.pend = 0u;
+}
+
+// A candidate's result: closest keeps the nearest (bvh.wgsl:268-272), occlusion stops at the first hit in range
+// that no subtraction shape removes (bvh.wgsl:334-341).  Returns true when the traversal is over.
+PT_DEV bool trav_apply(const DScene& sc, Trav& tv, bool hit, float ht, uint32_t sub) {
+    if (!tv.shadow) {
+        if (hit && ht < tv.bound && ht > PT_EPS) {
+            tv.bound = ht;
+            tv.slot = tv.pi;
+            tv.sub = sub;
+        }
+        return false;
+    }
+    if (hit && ht > PT_EPS && ht < tv.bound - PT_EPS)
+        if (sc.nneg == 0u || !inside_any_negative(sc, madd(tv.ray.o, tv.ray.d, ht))) {
+            tv.slot = 0u;
+            return true;
+        }
+    return false;
+}
+
+// One WALK step: walk inner nodes until the lane stands at a leaf primitive (same pops, pushes and guards as
+// trace_positive_walk / trace_shadow_walk), then test that primitive, or enter its marcher.  Returns the lane's
+// next state.
+template <bool FRAC>
+PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps) {
+    while (tv.pi >= tv.pend) {
+        PT_SITE(1);
+        if (!tv.have) {
+            if (tv.sp == 0) return LS_POST;
+            tv.sp -= 1;
+            StackEntry e = stack_get(st, tv.sp);
+            tv.cur = e.x;
+            tv.cur_t = __uint_as_float(e.y);
+        }
+        tv.have = false;
+        if (tv.shadow ? !(tv.cur_t < tv.bound) : (tv.cur_t >= tv.bound)) continue;
+        uint32_t cnt = tv.cur >> PT_REF_BITS, ref = tv.cur & PT_REF_MASK;
+        if (cnt > 0u) {
+            tv.pi = ref;
+            tv.pend = ref + cnt;
+        } else {
+            PT_SITE(2);
+            const DNodePair& nd = sc.pairs[ref];
+            float tl = intersect_aabb(tv.ray.o, tv.inv_dir, nd.lmin, nd.lmax);
+            float tr = intersect_aabb(tv.ray.o, tv.inv_dir, nd.rmin, nd.rmax);
+            uint32_t le = nd.lref | (nd.lcnt << PT_REF_BITS), re = nd.rref | (nd.rcnt << PT_REF_BITS);
+            // closest: far child pushed, near child continued, both only if nearer than the best hit;
+            // occlusion: left pushed, right continued, unconditionally (bvh.wgsl:283-300 / 346-353).
+            bool left_near = !tv.shadow && tl < tr;
+            uint32_t far_e = left_near ? re : le, near_e = left_near ? le : re;
+            float far_t = left_near ? tr : tl, near_t = left_near ? tl : tr;
+            if ((tv.shadow || far_t < tv.bound) && tv.sp < 31) {
+                stack_put(st, tv.sp, make_uint2(far_e, __float_as_uint(far_t)));
+                tv.sp += 1;
+            }
+            if ((tv.shadow || near_t < tv.bound) && tv.sp < 31) {
+                tv.cur = near_e;
+                tv.cur_t = near_t;
+                tv.have = true;
+            }
+        }
+    }
+    const DPrim& g = sc.prims[tv.pi];
+    const uint32_t type = g.type;
+    bool hit = false;
+    float ht = 0.0f;
+    uint32_t sub = 0u;
+    if (type == FIG_TORUS) {
+        if (march_begin_torus(tv.ray, g, tv.m)) return LS_TORUS;
+    } else if (type == FIG_MEBIUS) {
+        if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
+    } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
+        if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
+    } else if (type != FIG_SKIP) {
+        hit = intersect_closed(tv.ray, tv.inv_dir, g, ht, sub);
+    }
+    if (trav_apply(sc, tv, hit, ht, sub)) return LS_POST;
+    tv.pi += 1u;
+    return LS_WALK;
+}
+
+// One MARCH step of marcher `kind` (wave-uniform).
+template <bool FRAC>
+PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps) {
+    const DPrim& g = sc.prims[tv.pi];
+    int r;
+    if (kind == LS_TORUS) { PT_SITE(40); r = march_step_torus(tv.ray, g, tv.m); }
+    else if (kind == LS_MEBIUS) { PT_SITE(41); r = march_step_mebius(tv.ray, g, tv.m); }
+    else if (FRAC) { PT_SITE(42); r = march_step_fractal(tv.ray, g, march_steps, tv.m); }
+    else r = MARCH_MISS;
+    if (r == MARCH_GO) return kind;
+    if (trav_apply(sc, tv, r == MARCH_HIT, tv.m.t, 0u)) return LS_POST;
+    tv.pi += 1u;
+    return LS_WALK;
+}
+
+// Pixel jobs.  A lane is not tied to one pixel: when its pixel has all its samples it writes the pixel back and
+// claims the next unclaimed one from a launch-wide counter, so that a wave stays full until the frame runs out
+// of pixels, however unequal the pixels are (a Mandelbulb's silhouette costs a hundred times a background
+// pixel).  Job j is pixel (j & 255) of this launch's 16x16 block (j >> 8), 8x8 quadrant by quadrant; all the
+// samples of a pixel are still folded in order by the one lane that owns it, so results do not depend on which
+// lane that is.
+struct PixelJob { uint32_t tx, ty, px, py; size_t pix; };
+PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J) {
+    const uint32_t blk = (job >> 8) * P.part_world + P.part_rank, p = job & 255u;
+    const uint32_t bx = blk % P.blocks_x, by = blk / P.blocks_x, q = p >> 6, l = p & 63u;
+    J.tx = bx * 16u + (q & 1u) * 8u + (l & 7u);
+    J.ty = by * 16u + (q >> 1) * 8u + (l >> 3);
+    J.px = P.tile_x0 + J.tx;
+    J.py = P.tile_y0 + J.ty;
+    J.pix = (size_t)J.py * P.cam.width + J.px;
+    return J.tx < P.tile_w && J.ty < P.tile_h;
+}
+// Claims jobs until one lies inside the tile; loads that pixel's accumulator into the lane's LDS slots.
+PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate, float* px_f, PixelJob& J) {
+    uint32_t* px_u = (uint32_t*)px_f;
+    for (;;) {
+        if (!have_candidate) job = atomicAdd(P.job_counter, 1u);
+        have_candidate = false;
+        if (job >= P.total_jobs) return false;
+        if (job_pixel(P, job, J)) break;
+    }
+    float4 a = P.accum[J.pix];
+    px_f[0 * 64] = a.x; px_f[1 * 64] = a.y; px_f[2 * 64] = a.z;
+    if (P.m2) { px_f[3 * 64] = P.m2[J.pix * 3]; px_f[4 * 64] = P.m2[J.pix * 3 + 1]; px_f[5 * 64] = P.m2[J.pix * 3 + 2]; }
+    px_u[6 * 64] = 0u;
+    P.primary_ids[J.pix] = 0xFFFFFFFFu;
+    return true;
+}
+
+// Ends paths and starts new ones: while `ended`, folds the finished sample's radiance into the pixel's running
+// mean (path_trace.wgsl:181, :44-49), writes a finished pixel back and claims the next, and regenerates the
+// camera ray of the next sample (random.wgsl:12-14, camera.wgsl:6-19); then starts the closest-hit traversal of
+// `nray`.  `fresh`: the lane has just claimed `job` and has no sample to fold yet.  Returns the lane's next state.
+PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* px_f, uint32_t& job, bool fresh, bool ended,
+                          Ray nray, V3 thr, V3 rad, uint32_t rng, uint32_t bounce) {
+    const ptx_camera& cam = P.cam;
+    uint32_t* park_u = (uint32_t*)park;
+    uint32_t* px_u = (uint32_t*)px_f;
+    while (ended || fresh) {
+        PixelJob J;
+        uint32_t k_next = 0u;
+        if (!fresh) {
+            PT_SITE(36);
+            job_pixel(P, job, J);
+            const uint32_t k = px_u[6 * 64];
+            V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
+            V3 r = v3(dm::fmax_(rad.x, 0.0f), dm::fmax_(rad.y, 0.0f), dm::fmax_(rad.z, 0.0f));
+            float nn = dm::fmax_((float)(P.first_sample + k), 1.0f);
+            V3 delta = r - mean;
+            V3 nm = mean + vdivs(delta, nn);
+            if (P.m2) {
+                V3 d2 = r - nm;
+                px_f[3 * 64] = dm::fma_(delta.x, d2.x, px_f[3 * 64]);
+                px_f[4 * 64] = dm::fma_(delta.y, d2.y, px_f[4 * 64]);
+                px_f[5 * 64] = dm::fma_(delta.z, d2.z, px_f[5 * 64]);
+            }
+            px_f[0 * 64] = nm.x; px_f[1 * 64] = nm.y; px_f[2 * 64] = nm.z;
+            if (P.dbg_radiance && k < P.dbg_capacity) {
+                size_t o = ((size_t)k * P.tile_h * P.tile_w + (size_t)J.ty * P.tile_w + J.tx) * 3;
+                P.dbg_radiance[o] = r.x;
+                P.dbg_radiance[o + 1] = r.y;
+                P.dbg_radiance[o + 2] = r.z;
+            }
+            px_u[6 * 64] = k + 1u;
+            k_next = k + 1u;
+            if (k_next >= P.n) {  // pixel complete: write it back, claim another
+                P.accum[J.pix] = make_float4(nm.x, nm.y, nm.z, 1.0f);
+                if (P.m2) { P.m2[J.pix * 3] = px_f[3 * 64]; P.m2[J.pix * 3 + 1] = px_f[4 * 64]; P.m2[J.pix * 3 + 2] = px_f[5 * 64]; }
+                P.out_rgba8[J.pix] = tonemap_rgba8(cam, nm);
+                if (P.stats) atomicAdd(&P.stats[0], (unsigned long long)k_next);
+                if (!claim_pixel(P, job, false, px_f, J)) return LS_IDLE;
+                k_next = 0u;
+            }
+        } else {
+            job_pixel(P, job, J);
+        }
+        fresh = false;
+        rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + k_next) * 16777259u);
+        nray = generate_ray(cam, rng, (float)J.px, (float)J.py);
+        thr = v3(1.0f, 1.0f, 1.0f);
+        rad = v3(0.0f, 0.0f, 0.0f);
+        bounce = 0u;
+        ended = cam.max_bounces == 0u;
+    }
+    park[(PK_THR + 0) * 64] = thr.x; park[(PK_THR + 1) * 64] = thr.y; park[(PK_THR + 2) * 64] = thr.z;
+    park[(PK_RAD + 0) * 64] = rad.x; park[(PK_RAD + 1) * 64] = rad.y; park[(PK_RAD + 2) * 64] = rad.z;
+    park_u[PK_RNG * 64] = rng;
+    park_u[PK_MISC * 64] = bounce;  // csg attempt 0, lit 0
+    tv.ray = nray;
+    tv.inv_dir = vrcp(nray.d);
+    trav_begin(sc, tv, false, PT_MAX_T);
+    return LS_WALK;
+}
+
+// One POST step: everything between the end of a traversal and the start of the lane's next one
+// (path_trace.wgsl:63-179 around the two trace calls; bvh.wgsl:143-232 after the BVH loop).
+template <bool FRAC>
+PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* px_f, uint32_t& job, uint32_t& n_shadow) {
+    PT_SITE(43);
+    const ptx_camera& cam = P.cam;
+    uint32_t* park_u = (uint32_t*)park;
+    uint32_t* px_u = (uint32_t*)px_f;
+    V3 thr = v3(park[(PK_THR + 0) * 64], park[(PK_THR + 1) * 64], park[(PK_THR + 2) * 64]);
+    V3 rad = v3(park[(PK_RAD + 0) * 64], park[(PK_RAD + 1) * 64], park[(PK_RAD + 2) * 64]);
+    uint32_t rng = park_u[PK_RNG * 64];
+    const uint32_t misc = park_u[PK_MISC * 64];
+    uint32_t bounce = misc & 0xFFFFFFu, attempt = (misc >> 24) & 0x7Fu;
+    const bool lit = (misc >> 31) != 0u;
+    bool need_b = false, ended = false, new_ray = false;
+    Ray nray;
+    nray.o = v3(0.0f, 0.0f, 0.0f);
+    nray.d = v3(0.0f, 0.0f, 1.0f);
+    if (!tv.shadow) {
+        // bvh.wgsl:192-209: planes, tested linearly after the BVH.
+        for (uint32_t i = 0; i < sc.ninf; i++) {
+            PT_SITE(30);
+            const DPrim& g = sc.inf[i];
+            float ht;
+            uint32_t sub;
+            if (intersect_closed(tv.ray, tv.inv_dir, g, ht, sub) && ht > PT_EPS && ht < tv.bound) {
+                tv.bound = ht;
+                tv.slot = PT_SLOT_INF | i;
+                tv.sub = sub;
+            }
+        }
+        // bvh.wgsl:143-188: a hit inside a subtraction shape restarts the traversal behind that shape, up to 8 times.
+        if (sc.nneg > 0u && tv.slot != PT_SLOT_NONE && attempt < 8u) {
+            V3 hp = madd(tv.ray.o, tv.ray.d, tv.bound);
+            if (inside_any_negative(sc, hp)) {
+                float min_exit = PT_MAX_T;
+                for (uint32_t i = 0; i < sc.nneg; i++)
+                    if (is_inside_neg(sc.negs[i], hp)) min_exit = dm::fmin_(min_exit, find_exit_t(sc.negs[i], tv.ray));
+                if (!(min_exit >= PT_MAX_T)) {
+                    float advance = min_exit + PT_EPS * 2.0f;
+                    tv.ray.o = madd(tv.ray.o, tv.ray.d, advance);
+                    park_u[PK_MISC * 64] = bounce | ((attempt + 1u) << 24);
+                    trav_begin(sc, tv, false, PT_MAX_T);
+                    return LS_WALK;
+                }
+            }
+        }
+        PT_SITE(32);
+        px_u[7 * 64] += 1u;
+        const bool first = bounce == 0u;
+        uint32_t fig = 0xFFFFFFFFu;
+        if (tv.slot == PT_SLOT_NONE) {
+            rad = rad + thr * sample_skybox(sc, cam, tv.ray.d);
+            ended = true;
+        } else {
+            const DPrim& g = slot_prim(sc, tv.slot);
+            fig = g.fig;
+            const DShade& sh = sc.shade[fig];
+            const ptx_material mt = sh.mat;
+            bool need_uv = mt.texture_id >= 0;
+            HitFull h;
+            resolve_hit<FRAC>(tv.ray, tv.inv_dir, g, tv.bound, tv.sub, need_uv, &sh, &h);
+            V3 base_color = v3p(mt.base_color);
+            if (need_uv) {
+                V2 tuv;
+                tuv.x = h.uv.x * sh.texture_scale;
+                tuv.y = h.uv.y * sh.texture_scale;
+                base_color = base_color * sample_texture(sc, mt.texture_id, tuv);
+            }
+            if (mt.emission_strength > 0.0f) {  // path_trace.wgsl:83-87
+                V3 le = v3p(mt.emission) * mt.emission_strength;
+                rad = rad + thr * le;
+                ended = true;
+            } else {
+                V3 wo = -tv.ray.d;
+                V3 n = h.normal;
+                if (dot(n, wo) < 0.0f) n = -n;
+                if (mt.transmission > 0.5f) {  // path_trace.wgsl:97-105
+                    PT_SITE(37);
+                    V3 dir;
+                    if (!sample_glass(rng, wo, n, mt.ior, dir)) {
+                        ended = true;
+                    } else {
+                        thr = thr * base_color;
+                        nray.o = madd(h.pos, dir, PT_EPS * 2.0f);
+                        nray.d = dir;
+                        bounce += 1u;
+                        new_ray = true;
+                    }
+                } else {
+                    V3 hpos = h.pos;
+                    park[(PK_HPOS + 0) * 64] = hpos.x; park[(PK_HPOS + 1) * 64] = hpos.y; park[(PK_HPOS + 2) * 64] = hpos.z;
+                    park[(PK_N + 0) * 64] = n.x; park[(PK_N + 1) * 64] = n.y; park[(PK_N + 2) * 64] = n.z;
+                    park[(PK_BASE + 0) * 64] = base_color.x; park[(PK_BASE + 1) * 64] = base_color.y; park[(PK_BASE + 2) * 64] = base_color.z;
+                    park_u[PK_FIG * 64] = fig;
+                    park[(PK_WO + 0) * 64] = wo.x; park[(PK_WO + 1) * 64] = wo.y; park[(PK_WO + 2) * 64] = wo.z;
+                    need_b = true;
+                    if (mt.roughness > 0.04f) {  // path_trace.wgsl:108-154
+                        PT_SITE(33);
+                        MatD mat;
+                        mat.base_color = base_color;
+                        mat.metallic = mt.metallic;
+                        mat.roughness = mt.roughness;
+                        mat.ior = mt.ior;
+                        const uint32_t num_lights = sc.nlight > 0u ? sc.nlight : 1u;  // empty list = one-element placeholder
+                        float pick = rand_f32(rng);
+                        uint32_t light_pick = (uint32_t)(pick * (float)num_lights);
+                        uint32_t li = light_pick < num_lights - 1u ? light_pick : num_lights - 1u;
+                        float r1 = rand_f32(rng), r2 = rand_f32(rng);
+                        if (sc.nlight > 0u) {
+                            const DLight L = sc.lights[li];
+                            float cos_theta = 1.0f - 2.0f * r1;  // lighting.wgsl:6-20
+                            float sin_theta = dm::sqrt_(1.0f - cos_theta * cos_theta);
+                            float sp, cp;
+                            dm::sincos_(PT_TWO_PI * r2, &sp, &cp);
+                            V3 local_point = v3(sin_theta * cp, sin_theta * sp, cos_theta) * L.radius;
+                            V3 lpos = v3p(L.pos);
+                            V3 light_point = lpos + local_point;
+                            V3 to_light = light_point - hpos;
+                            float light_dist = length(to_light);
+                            V3 light_dir = vdivs(to_light, light_dist);
+                            float n_dot_l = dot(n, light_dir);
+                            if (n_dot_l > 0.0f) {
+                                PT_SITE(34);
+                                V3 light_normal = normalize(light_point - lpos);
+                                float cos_light = dm::abs_(dot(-light_dir, light_normal));
+                                float light_solid_pdf = cos_light <= 0.0f ? 0.0f : dm::div_(L.area_pdf * (light_dist * light_dist), cos_light);
+                                V3 brdf = eval_brdf(wo, light_dir, n, mat);
+                                float brdf_pdf_val = n_dot_l * PT_INV_PI;
+                                float pa = light_solid_pdf * (float)num_lights;
+                                float a2 = pa * pa, b2 = brdf_pdf_val * brdf_pdf_val;  // mis.wgsl:3-7
+                                float w = dm::div_(a2, dm::fmax_(a2 + b2, 1e-10f));
+                                V3 contrib = vdivs(thr * v3p(L.le) * brdf * n_dot_l * w, pa);
+                                park[(PK_CONTRIB + 0) * 64] = contrib.x; park[(PK_CONTRIB + 1) * 64] = contrib.y; park[(PK_CONTRIB + 2) * 64] = contrib.z;
+                                n_shadow += 1u;
+                                if (first) { PixelJob J; job_pixel(P, job, J); P.primary_ids[J.pix] = fig; }
+                                park[(PK_THR + 0) * 64] = thr.x; park[(PK_THR + 1) * 64] = thr.y; park[(PK_THR + 2) * 64] = thr.z;
+                                park[(PK_RAD + 0) * 64] = rad.x; park[(PK_RAD + 1) * 64] = rad.y; park[(PK_RAD + 2) * 64] = rad.z;
+                                park_u[PK_RNG * 64] = rng;
+                                park_u[PK_MISC * 64] = bounce | (light_solid_pdf > 0.0f ? 0x80000000u : 0u);
+                                tv.ray.o = madd(hpos, n, PT_EPS * 2.0f);
+                                tv.ray.d = light_dir;
+                                tv.inv_dir = vrcp(light_dir);
+                                trav_begin(sc, tv, true, light_dist);
+                                return LS_WALK;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (first) { PixelJob J; job_pixel(P, job, J); P.primary_ids[J.pix] = fig; }
+    } else {
+        // bvh.wgsl:212-232: the plane list of the occlusion query, unless the BVH already gave an occluder.
+        bool occluded = tv.slot != PT_SLOT_NONE;
+        for (uint32_t i = 0; i < sc.ninf && !occluded; i++) {
+            PT_SITE(30);
+            const DPrim& g = sc.inf[i];
+            float ht;
+            uint32_t sub;
+            if (intersect_closed(tv.ray, tv.inv_dir, g, ht, sub) && ht > PT_EPS && ht < tv.bound - PT_EPS)
+                if (sc.nneg == 0u || !inside_any_negative(sc, madd(tv.ray.o, tv.ray.d, ht))) occluded = true;
+        }
+        if (!occluded && lit)  // path_trace.wgsl:148: only when light_solid_pdf > 0
+            rad = rad + v3(park[(PK_CONTRIB + 0) * 64], park[(PK_CONTRIB + 1) * 64], park[(PK_CONTRIB + 2) * 64]);
+        need_b = true;
+    }
+    if (need_b) {  // path_trace.wgsl:156-178
+        PT_SITE(35);
+        V3 hpos = v3(park[(PK_HPOS + 0) * 64], park[(PK_HPOS + 1) * 64], park[(PK_HPOS + 2) * 64]);
+        V3 n = v3(park[(PK_N + 0) * 64], park[(PK_N + 1) * 64], park[(PK_N + 2) * 64]);
+        V3 wo = v3(park[(PK_WO + 0) * 64], park[(PK_WO + 1) * 64], park[(PK_WO + 2) * 64]);
+        const ptx_material& mt = sc.shade[park_u[PK_FIG * 64]].mat;
+        MatD mat;
+        mat.base_color = v3(park[(PK_BASE + 0) * 64], park[(PK_BASE + 1) * 64], park[(PK_BASE + 2) * 64]);
+        mat.metallic = mt.metallic;
+        mat.roughness = mt.roughness;
+        mat.ior = mt.ior;
+        V3 wi, weight;
+        if (!sample_brdf(rng, wo, n, mat, wi, weight)) {
+            ended = true;
+        } else {
+            thr = thr * weight;
+            nray.o = madd(hpos, wi, PT_EPS * 2.0f);
+            nray.d = wi;
+            if (bounce >= 3u) {  // path_trace.wgsl:166-172
+                float survival = dm::fmin_(dm::fmax_(thr.x, dm::fmax_(thr.y, thr.z)), 0.95f);
+                if (rand_f32(rng) > survival) ended = true;
+                else thr = vdivs(thr, survival);
+            }
+            if (!ended) {
+                float lum = dot(thr, v3(0.2126f, 0.7152f, 0.0722f));
+                if (lum > cam.firefly_clamp) thr = thr * dm::div_(cam.firefly_clamp, lum);
+                bounce += 1u;
+                new_ray = true;
+            }
+        }
+    }
+    if (new_ray && bounce >= cam.max_bounces) ended = true;  // path_trace.wgsl:63
+    return next_path(sc, P, tv, park, px_f, job, false, ended, nray, thr, rad, rng, bounce);
+}

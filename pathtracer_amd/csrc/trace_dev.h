@@ -36,15 +36,16 @@ typedef uint2 StackEntry;
 #define PT_LDS_STACK 4u
 #endif
 struct WalkStack {
-    StackEntry* lds;  // entry e < PT_LDS_STACK of this lane at lds[e * 64]
-    StackEntry* glb;  // entry e >= PT_LDS_STACK at glb[(e - PT_LDS_STACK) * 64]
+    StackEntry* lds;  // entry e < nl of this lane at lds[e * 64]
+    StackEntry* glb;  // entry e >= nl at glb[(e - nl) * 64]
+    uint32_t nl;      // PT_LDS_STACK, or the whole stack depth for the LDS-staged kernels (no global part)
 };
 PT_DEV StackEntry stack_get(const WalkStack& w, int sp) {
-    return (uint32_t)sp < PT_LDS_STACK ? w.lds[sp * 64] : w.glb[(sp - (int)PT_LDS_STACK) * 64];
+    return (uint32_t)sp < w.nl ? w.lds[sp * 64] : w.glb[(sp - (int)w.nl) * 64];
 }
 PT_DEV void stack_put(const WalkStack& w, int sp, StackEntry e) {
-    if ((uint32_t)sp < PT_LDS_STACK) w.lds[sp * 64] = e;
-    else w.glb[(sp - (int)PT_LDS_STACK) * 64] = e;
+    if ((uint32_t)sp < w.nl) w.lds[sp * 64] = e;
+    else w.glb[(sp - (int)w.nl) * 64] = e;
 }
 
 // Two loop shapes run the same per-lane sequence of box and primitive tests (the reference's):

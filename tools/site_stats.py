@@ -16,7 +16,7 @@ if os.environ.get("PTX355_LIB"):
 from pathtracer_amd.device import PathTracer  # noqa: E402
 
 NAMES = {0: "bounce_step", 1: "walk step", 2: "pair test", 3: "serve round", 30: "plane test", 32: "resolve+shadeA", 33: "NEE setup",
-         34: "NEE eval+shadow", 35: "sample_brdf", 36: "finalize sample", 37: "glass", 40: "torus step", 41: "mebius step", 42: "fractal step"}
+         34: "NEE eval+shadow", 35: "sample_brdf", 36: "finalize sample", 37: "glass", 43: "POST step", 40: "torus step", 41: "mebius step", 42: "fractal step"}
 TYPES = ["sphere", "plane", "cube", "cylinder", "cone", "torus", "disc", "triangle", "skybox", "mandelbulb", "julia", "ellipsoid",
          "paraboloid", "hyperboloid", "mebius", "pyramid", "tetrahedron", "nop"]
 for i, t in enumerate(TYPES):
@@ -46,7 +46,7 @@ pt.sync()
 fn(buf.ctypes.data, 96)
 ms, _ = pt.kernel_time()
 st = pt.stats()
-wb = float(buf[0])
+wb = float(buf[0]) or st["bounces"] / 64.0  # the scheduled kernels have no common bounce step: normalise per 64 lane-bounces
 print(f"{name} {w}x{h} n={n} quads={quads} kernel={pt.kernel_name()} {ms:.1f} ms lane-bounces/wave-bounce={st['bounces'] / wb:.1f} "
       f"paths={st['paths']} bounces={st['bounces']} shadow_rays={st['shadow_rays']}")
 pairs, tris = float(buf[2 * 2 + 1]), float(buf[2 * 17 + 1])
