@@ -22,6 +22,9 @@
 #define PTX_BLOCK 256
 #define PTX_WAVES_PER_BLOCK 4
 #define PT_PIXEL_FIELDS 9u  // per-lane LDS slots: mean xyz, M2 xyz, sample index, path-bounces, primary id
+#ifndef PTX_CLAIM_LDS
+#define PTX_CLAIM_LDS true  // the lockstep LDS kernels claim pixels dynamically
+#endif
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
@@ -51,7 +54,9 @@ PT_DEV void copy_to_lds(void* dst, const void* src, uint32_t bytes) {
 // LDS_SCENE: the whole scene (primitives, planes, node pairs, shading records, lights, subtraction
 // shapes) is small enough to be staged in LDS once per workgroup; every later scene read is then an
 // LDS read (~100 cycles) instead of a dependent L1/L2 round trip, which is what the traversal waits on.
-template <bool LDS_SCENE, bool FRAC>
+// CLAIM: the grid is sized to the GPU and a lane whose pixel has all its samples claims the next unclaimed
+// pixel (job_pixel / claim_pixel in sched_dev.h) instead of idling until the slowest pixel of its wave is done.
+template <bool LDS_SCENE, bool FRAC, bool CLAIM>
 PT_DEV void trace_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -78,31 +83,28 @@ PT_DEV void trace_body(const TraceParams& P) {
         __syncthreads();
     }
 
-    const uint32_t blk = xcd_remap(blockIdx.x, P.n_blocks) * P.part_world + P.part_rank;
-    const uint32_t bx = blk % P.blocks_x, by = blk / P.blocks_x;
-    const uint32_t tx = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ty = by * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const bool inside = tx < P.tile_w && ty < P.tile_h;
-    const uint32_t px = P.tile_x0 + tx, py = P.tile_y0 + ty;
-    const size_t pix = (size_t)py * P.cam.width + px;
-
     // Per-pixel state that is only touched when a path ends (running mean, M2, sample index, tallies)
     // lives in LDS, one lane-interleaved slot per field, so it does not occupy registers during traversal.
     float* px_f = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u) + (size_t)wave * (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 64u + lane;
     uint32_t* px_u = (uint32_t*)px_f;
-    bool active = inside && P.n > 0u;
-    {
-        V3 mean = v3(0.0f, 0.0f, 0.0f), m2 = v3(0.0f, 0.0f, 0.0f);
-        if (active) {
-            float4 a = P.accum[pix];
-            mean = v3(a.x, a.y, a.z);
-            if (P.m2) m2 = v3(P.m2[pix * 3], P.m2[pix * 3 + 1], P.m2[pix * 3 + 2]);
+    // The lane's pixel: with CLAIM a job number (coordinates are recomputed from it when a path ends), else fixed.
+    uint32_t job = CLAIM ? blockIdx.x * PTX_BLOCK + threadIdx.x
+                         : (xcd_remap(blockIdx.x, P.n_blocks) << 8) | threadIdx.x;
+    PixelJob J;
+    bool active = false;
+    px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
+    px_u[6 * 64] = 0u;            // k: samples of the current pixel finished
+    px_u[7 * 64] = 0u;            // path-bounces
+    px_u[8 * 64] = 0xFFFFFFFFu;   // primary hit of the latest sample
+    if (P.n > 0u) {
+        if (CLAIM) {
+            active = claim_pixel(P, job, true, px_f, J);
+        } else if (job_pixel(P, job, J)) {
+            active = true;
+            float4 a = P.accum[J.pix];
+            px_f[0 * 64] = a.x; px_f[1 * 64] = a.y; px_f[2 * 64] = a.z;
+            if (P.m2) { px_f[3 * 64] = P.m2[J.pix * 3]; px_f[4 * 64] = P.m2[J.pix * 3 + 1]; px_f[5 * 64] = P.m2[J.pix * 3 + 2]; }
         }
-        px_f[0 * 64] = mean.x; px_f[1 * 64] = mean.y; px_f[2 * 64] = mean.z;
-        px_f[3 * 64] = m2.x; px_f[4 * 64] = m2.y; px_f[5 * 64] = m2.z;
-        px_u[6 * 64] = 0u;            // k: samples finished
-        px_u[7 * 64] = 0u;            // path-bounces
-        px_u[8 * 64] = 0xFFFFFFFFu;   // primary hit of the latest sample
     }
     uint32_t n_shadow = 0;
     PathState ps;
@@ -113,8 +115,8 @@ PT_DEV void trace_body(const TraceParams& P) {
     ps.ray.o = v3(0.0f, 0.0f, 0.0f);
     ps.ray.d = v3(0.0f, 0.0f, 1.0f);
     if (active) {
-        ps.rng = pcg_hash(px + py * 65536u + P.first_frame * 16777259u);  // random.wgsl:12-14
-        ps.ray = generate_ray(P.cam, ps.rng, (float)px, (float)py);
+        ps.rng = pcg_hash(J.px + J.py * 65536u + P.first_frame * 16777259u);  // random.wgsl:12-14
+        ps.ray = generate_ray(P.cam, ps.rng, (float)J.px, (float)J.py);
     }
 #ifdef PTX_PHASE_TIMING
     for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
@@ -136,6 +138,7 @@ PT_DEV void trace_body(const TraceParams& P) {
         if (done) {
             PT_SITE(36);
             // path_trace.wgsl:181 and :44-49
+            job_pixel(P, job, J);
             const uint32_t k = px_u[6 * 64];
             V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
             V3 rad = v3(dm::fmax_(ps.radiance.x, 0.0f), dm::fmax_(ps.radiance.y, 0.0f), dm::fmax_(ps.radiance.z, 0.0f));
@@ -150,7 +153,7 @@ PT_DEV void trace_body(const TraceParams& P) {
             }
             px_f[0 * 64] = nm.x; px_f[1 * 64] = nm.y; px_f[2 * 64] = nm.z;
             if (P.dbg_radiance && k < P.dbg_capacity) {
-                size_t r = ((size_t)k * P.tile_h * P.tile_w + (size_t)ty * P.tile_w + tx) * 3;
+                size_t r = ((size_t)k * P.tile_h * P.tile_w + (size_t)J.ty * P.tile_w + J.tx) * 3;
                 P.dbg_radiance[r] = rad.x;
                 P.dbg_radiance[r + 1] = rad.y;
                 P.dbg_radiance[r + 2] = rad.z;
@@ -158,14 +161,23 @@ PT_DEV void trace_body(const TraceParams& P) {
             px_u[6 * 64] = k + 1u;
             px_u[7 * 64] += local_bounces;
             local_bounces = 0u;
-            if (k + 1u < P.n) {
-                ps.rng = pcg_hash(px + py * 65536u + (P.first_frame + k + 1u) * 16777259u);
-                ps.ray = generate_ray(P.cam, ps.rng, (float)px, (float)py);
+            uint32_t k_next = k + 1u;
+            if (k_next >= P.n) {  // pixel complete: write it back; with CLAIM go on with another pixel
+                P.accum[J.pix] = make_float4(nm.x, nm.y, nm.z, 1.0f);
+                if (P.m2) { P.m2[J.pix * 3] = px_f[3 * 64]; P.m2[J.pix * 3 + 1] = px_f[4 * 64]; P.m2[J.pix * 3 + 2] = px_f[5 * 64]; }
+                P.out_rgba8[J.pix] = tonemap_rgba8(P.cam, nm);
+                P.primary_ids[J.pix] = px_u[8 * 64];
+                if (P.stats) atomicAdd(&P.stats[0], (unsigned long long)k_next);
+                active = CLAIM && claim_pixel(P, job, false, px_f, J);
+                px_u[8 * 64] = 0xFFFFFFFFu;
+                k_next = 0u;
+            }
+            if (active) {
+                ps.rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + k_next) * 16777259u);
+                ps.ray = generate_ray(P.cam, ps.rng, (float)J.px, (float)J.py);
                 ps.throughput = v3(1.0f, 1.0f, 1.0f);
                 ps.radiance = v3(0.0f, 0.0f, 0.0f);
                 ps.bounce = 0u;
-            } else {
-                active = false;
             }
         }
         PT_TICK(5);
@@ -174,17 +186,9 @@ PT_DEV void trace_body(const TraceParams& P) {
     if (lane == 0u && P.stats)
         for (int i = 0; i < 6; i++) atomicAdd(&P.stats[4 + i], (unsigned long long)ps.tick_acc[i]);
 #endif
-    if (inside && P.n > 0u) {
-        V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
-        P.accum[pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
-        if (P.m2) { P.m2[pix * 3] = px_f[3 * 64]; P.m2[pix * 3 + 1] = px_f[4 * 64]; P.m2[pix * 3 + 2] = px_f[5 * 64]; }
-        P.out_rgba8[pix] = tonemap_rgba8(P.cam, mean);
-        P.primary_ids[pix] = px_u[8 * 64];
-    }
-    const uint32_t k = px_u[6 * 64], n_bounce = px_u[7 * 64];
-    uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow), sp = wave_sum(k);
-    if (lane == 0u && P.stats) {
-        atomicAdd(&P.stats[0], (unsigned long long)sp);
+    const uint32_t n_bounce = px_u[7 * 64];
+    uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
+    if (lane == 0u && P.stats) {  // paths were added pixel by pixel
         atomicAdd(&P.stats[1], (unsigned long long)sb);
         atomicAdd(&P.stats[2], (unsigned long long)ss);
     }
@@ -300,10 +304,10 @@ PT_DEV void sched_body(const TraceParams& P) {
 
 // Four variants: scene records in global memory or staged in LDS; with or without the fractal marchers.
 // Without them the kernel fits 128 VGPRs (4 waves per SIMD); with them 3 waves.
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false, PTX_CLAIM_LDS>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true, PTX_CLAIM_LDS>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_sched_kernel(const TraceParams P) { sched_body<false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_sched_kernel_lds(const TraceParams P) { sched_body<true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_frac(const TraceParams P) { sched_body<false, true>(P); }
@@ -874,9 +878,10 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.lds_stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
     // The scheduled kernels run a grid sized to the GPU (4 workgroups per compute unit fit at most) whose lanes
     // claim pixels from a counter that starts behind the grid's own first jobs.
-    const uint32_t grid = c->sched ? (P.n_blocks < c->n_cu * 4u ? P.n_blocks : c->n_cu * 4u) : P.n_blocks;
+    const bool claim = c->sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u);
+    const uint32_t grid = claim ? (P.n_blocks < c->n_cu * 4u ? P.n_blocks : c->n_cu * 4u) : P.n_blocks;
     { int rc = ensure_spill(c, (size_t)grid * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
-    if (c->sched) {
+    if (claim) {
         P.job_counter = (uint32_t*)&c->stats[15];
         P.total_jobs = P.n_blocks * 256u;
         HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
