@@ -196,15 +196,6 @@ PT_DEV void trace_body(const TraceParams& P) {
 
 // The wave-scheduled kernel body (sched_dev.h): same buffers and results as trace_body; the grid is sized to
 // the GPU, not to the frame, and lanes claim pixels as they go.
-#ifndef SCH_WALK_SHARE
-#define SCH_WALK_SHARE 4u   // WALK is served when its lanes are at least 1/4 of the live lanes
-#endif
-#ifndef SCH_POST_SHARE
-#define SCH_POST_SHARE 2u   // POST: 1/2
-#endif
-#ifndef SCH_MARCH_SHARE
-#define SCH_MARCH_SHARE 4u  // a marcher: 1/4
-#endif
 static_assert(SC_PIXEL_FIELDS + SC_PARK_FIELDS == PT_PIXEL_FIELDS + PT_PARK_FIELDS, "both kernel families share one LDS budget");
 template <bool LDS_SCENE, bool FRAC>
 PT_DEV void sched_body(const TraceParams& P) {
@@ -258,10 +249,11 @@ PT_DEV void sched_body(const TraceParams& P) {
             S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u);
         }
     }
-    // The scheduler.  A state is served when enough of the wave's live lanes wait in it: WALK steps are cheap
-    // and feed the other states, so they run from a quarter of the live lanes; the long POST step waits for
-    // half; a marcher for a quarter and then keeps stepping while three quarters of its lanes are still
-    // marching.  When no state reaches its share the fullest one is served, so every round makes progress.
+    // The scheduler.  A state is served when at least 1/share of the wave's live lanes wait in it, WALK before
+    // POST before the fullest marcher; a marcher then keeps stepping while three quarters of its lanes are
+    // still marching.  When no state reaches its share the fullest one is served, so every round makes
+    // progress.  The shares are set per scene class by the host (measured): meshes walk whenever any lane can
+    // (64, 2, 4), meshes with ray-marched figures 8, 2, 4, fractal scenes 8, 4, 4, small scenes with a Moebius strip 4, 2, 4.
     for (;;) {
         uint32_t pop[LS_COUNT];
         uint32_t live = 0u, fullest = LS_IDLE, fullest_n = 0u, march = LS_IDLE, march_n = 0u;
@@ -274,14 +266,14 @@ PT_DEV void sched_body(const TraceParams& P) {
         }
         if (live == 0u) break;
         uint32_t pick = fullest;
-        if (pop[LS_WALK] * SCH_WALK_SHARE >= live) pick = LS_WALK;
-        else if (pop[LS_POST] * SCH_POST_SHARE >= live) pick = LS_POST;
-        else if (march_n * SCH_MARCH_SHARE >= live) pick = march;
+        if (pop[LS_WALK] * P.share_walk >= live) pick = LS_WALK;
+        else if (pop[LS_POST] * P.share_post >= live) pick = LS_POST;
+        else if (march_n * P.share_march >= live) pick = march;
         if (pick == LS_WALK) {
             for (;;) {
                 if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
-                if (w == 0u || w * SCH_WALK_SHARE < live) break;
+                if (w == 0u || w * P.share_walk < live) break;
             }
         } else if (pick == LS_POST) {
             if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, px_f, job, n_shadow);
@@ -446,6 +438,7 @@ struct ptx_ctx {
     uint32_t dbg_cap = 0;
     unsigned long long* stats = nullptr;
     bool sched = false;           // the uploaded scene runs the wave-scheduled kernels
+    uint32_t shares[3] = {4u, 2u, 4u};  // their scheduling shares (walk, post, march)
     uint32_t n_cu = 0;            // compute units of the device
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
     size_t spill_waves = 0;
@@ -804,6 +797,17 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     c->sc = sc;
     c->have_scene = true;
     c->sched = pick_sched(sc, dprims);
+    {
+        const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {8u, 4u, 4u}, small[3] = {4u, 2u, 4u};
+        bool marchers = false;
+        for (const DPrim& g : dprims) marchers = marchers || g.type == FIG_TORUS || g.type == FIG_MEBIUS || g.type == FIG_MANDELBULB || g.type == FIG_JULIA;
+        const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
+        memcpy(c->shares, pick, sizeof(c->shares));
+        if (const char* e = getenv("PTX355_SHARES")) {  // measurement runs: "walk,post,march"
+            unsigned w = 0, p = 0, m = 0;
+            if (sscanf(e, "%u,%u,%u", &w, &p, &m) == 3 && w && p && m) { c->shares[0] = w; c->shares[1] = p; c->shares[2] = m; }
+        }
+    }
     return PTX_OK;
 }
 
@@ -884,6 +888,7 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     if (claim) {
         P.job_counter = (uint32_t*)&c->stats[15];
         P.total_jobs = P.n_blocks * 256u;
+        P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
     }
     if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }

@@ -35,6 +35,7 @@ struct TraceParams {
     unsigned long long* stats;  // paths, bounces, shadow rays
     uint32_t* job_counter;  // scheduled kernels: next unclaimed pixel job
     uint32_t total_jobs;    // n_blocks * 256
+    uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
 };
 
 enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS = 4, LS_MANDEL = 5, LS_JULIA = 6, LS_COUNT = 7 };
