@@ -32,20 +32,21 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # packed v_pk_fma_f32; 78.6 for one FMA per lane 
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(fx_name: str, w: int, h: int, spp: int):
-    """The CPU oracle on a bounded sample of the same workload, timed on this host's cores; also returns the
-    oracle's work counters (the algorithmic flop figure comes from them)."""
+def cpu_baseline(scene, cam, label: str, spp: int, tile=None):
+    """The CPU oracle on a bounded sample of the same workload (same scene buffers, same camera), timed on this
+    host's cores; also returns the oracle's work counters (the algorithmic flop figure comes from them)."""
     from oracle import host_prep as hp, oracle as orc
-    sb = hp.prepare_fixture(os.path.join(ROOT, "data", "scenes", f"{fx_name}.npz"))
-    cam = hp.camera_to_gpu(sb.camera, w, h)
+    b = scene.buffers()
+    sb = hp.SceneBuffers(b["figs"], b["mats"], b["nodes"], b["prims"], b["lights"], b["infinite"], b["tex_pixels"], b["tex_infos"], None)
     threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     osc = orc.OracleScene(sb)
     t0 = time.perf_counter()
-    r = orc.render(osc, cam, spp, counters=True, threads=threads)
+    r = orc.render(osc, cam, spp, counters=True, threads=threads, tile=tile)
     dt = time.perf_counter() - t0
     c = r["counters"]
+    where = "whole frame" if tile is None else f"tile x0={tile[0]} y0={tile[1]} {tile[2]}x{tile[3]}"
     return {"value": round(c["paths"] / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": f"{fx_name} {w}x{h}, frames 0..{spp - 1} ({c['paths']} paths, {dt:.1f} s wall)",
+            "sample": f"{label}: {where}, frames 0..{spp - 1} ({c['paths']} paths, {dt:.1f} s wall)",
             "gpath_bounce_per_s": round(c["bounces"] / dt / 1e9, 6)}, c, orc.counted_flops(c)
 
 
@@ -148,10 +149,10 @@ def main():
         }
         cpu, flops_per_bounce = None, None
         if not args.no_cpu_baseline:
-            cpu_spp = {"cornell": 4, "teapot": 2, "fractals": 1, "all_mesh": 1}[args.workload]
-            if args.workload != "all_mesh":  # the 10 M-triangle scene is not rebuilt by the numpy checker
-                cpu, cnt, flops = cpu_baseline(fx_name, w, h, cpu_spp)
-                flops_per_bounce = flops / max(cnt["bounces"], 1)
+            # bounded CPU samples: whole frames, 10-30 s of work on 16 cores
+            cpu_spp, cpu_tile = {"cornell": (64, None), "teapot": (24, None), "fractals": (8, None), "all_mesh": (4, None)}[args.workload]
+            cpu, cnt, flops = cpu_baseline(scene, cam, label, cpu_spp, cpu_tile)
+            flops_per_bounce = flops / max(cnt["bounces"], 1)
         avg_ms = kernel_ms / max(launches, 1)
         roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": pt.kernel_name(),
                 "kernel_avg_ms": round(avg_ms, 3), "launches": launches, "traffic": None}
@@ -166,11 +167,24 @@ def main():
         stream_bytes = w * h * (16 + 16 + 4 + 4)
         roof["hbm_streaming"] = {"bytes_per_launch": stream_bytes, "achieved_gbs": round(stream_bytes / (avg_ms * 1e-3) / 1e9, 3),
                                  "peak_gbs": PEAK_HBM_GBS}
+        bf = os.path.join(ROOT, "profiles", "bvh_fetch.json")
+        if args.workload == "all_mesh" and os.path.exists(bf):
+            # The mesh workload is bound by dependent BVH record fetches, not by arithmetic: its roofline is the
+            # algorithmic record bytes (64 B per node pair visited and per triangle tested, counted by a
+            # diagnostic build on this same scene) over the kernel time, against HBM peak.
+            b = json.load(open(bf))
+            if b.get("mesh_quads") == args.mesh_quads:
+                per_bounce = b["bytes_per_path_bounce"]
+                ach = per_bounce * bounces / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": round(ach, 2), "frac": round(ach / PEAK_HBM_GBS, 5),
+                        "traffic": b.get("hbm_bytes_per_launch"), "kernel": pt.kernel_name(), "kernel_avg_ms": round(avg_ms, 3),
+                        "launches": launches, "bvh_bytes_per_path_bounce": per_bounce,
+                        "valu": {k: roof.get(k) for k in ("achieved", "frac", "flops_per_path_bounce")}}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf))
-                if t.get("workload") == args.workload and t.get("spp_per_step") == spp:
+                if t.get("workload") == args.workload and t.get("spp_per_step") == spp and roof.get("traffic") is None:
                     roof["traffic"] = t.get("hbm_bytes_per_launch")
             except Exception:
                 pass
