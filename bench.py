@@ -186,6 +186,8 @@ def main():
                 t = json.load(open(tf))
                 if t.get("workload") == args.workload and t.get("spp_per_step") == spp and roof.get("traffic") is None:
                     roof["traffic"] = t.get("hbm_bytes_per_launch")
+                    if t.get("valu_issue"):  # what the VALU counters of the committed profile say about this same launch
+                        roof["valu_issue_profiled"] = {k: t["valu_issue"][k] for k in ("valu_busy_frac", "lane_utilisation")}
             except Exception:
                 pass
         out["roofline"] = roof
