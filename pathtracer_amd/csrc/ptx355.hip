@@ -439,7 +439,10 @@ struct ptx_ctx {
     unsigned long long* stats = nullptr;
     bool sched = false;           // the uploaded scene runs the wave-scheduled kernels
     uint32_t shares[3] = {4u, 2u, 4u};  // their scheduling shares (walk, post, march)
+    uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
+    uint2* wave_tiles = nullptr;  // claim state of every wave of the largest grid so far
+    size_t wave_tiles_n = 0;
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
     size_t spill_waves = 0;
     // timing
@@ -594,6 +597,7 @@ void ptx_destroy(ptx_ctx* c) {
     free_scene(c);
     free_frame(c);
     if (c->stats) (void)hipFree(c->stats);
+    if (c->wave_tiles) (void)hipFree(c->wave_tiles);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -803,6 +807,8 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
         for (const DPrim& g : dprims) marchers = marchers || g.type == FIG_TORUS || g.type == FIG_MEBIUS || g.type == FIG_MANDELBULB || g.type == FIG_JULIA;
         const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
         memcpy(c->shares, pick, sizeof(c->shares));
+        c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
+        if (const char* e = getenv("PTX355_CLAIM_TILE")) c->claim_tile = atoi(e) > 1 ? 64u : 1u;
         if (const char* e = getenv("PTX355_SHARES")) {  // measurement runs: "walk,post,march"
             unsigned w = 0, p = 0, m = 0;
             if (sscanf(e, "%u,%u,%u", &w, &p, &m) == 3 && w && p && m) { c->shares[0] = w; c->shares[1] = p; c->shares[2] = m; }
@@ -886,8 +892,17 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     const uint32_t grid = claim ? (P.n_blocks < c->n_cu * 4u ? P.n_blocks : c->n_cu * 4u) : P.n_blocks;
     { int rc = ensure_spill(c, (size_t)grid * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
     if (claim) {
+        const size_t waves = (size_t)grid * PTX_WAVES_PER_BLOCK;
+        if (waves > c->wave_tiles_n) {
+            if (c->wave_tiles) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->wave_tiles); c->wave_tiles = nullptr; c->wave_tiles_n = 0; }
+            HIP_TRY(c, hipMalloc((void**)&c->wave_tiles, waves * sizeof(uint2)));
+            c->wave_tiles_n = waves;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->wave_tiles, 0, waves * sizeof(uint2), c->stream));
+        P.wave_tiles = c->wave_tiles;
         P.job_counter = (uint32_t*)&c->stats[15];
         P.total_jobs = P.n_blocks * 256u;
+        P.claim_tile = c->claim_tile;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
     }

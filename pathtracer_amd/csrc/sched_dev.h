@@ -33,7 +33,9 @@ struct TraceParams {
     float* dbg_radiance;  // null unless capture is enabled
     uint32_t dbg_capacity;
     unsigned long long* stats;  // paths, bounces, shadow rays
-    uint32_t* job_counter;  // scheduled kernels: next unclaimed pixel job
+    uint32_t* job_counter;  // next unclaimed 64-pixel tile of jobs (launch-wide)
+    uint2* wave_tiles;      // per wave of the grid: {next job, end} of the tile it is handing out to its lanes
+    uint32_t claim_tile;    // jobs a wave takes from job_counter at a time: 64, or 1 (lanes claim single pixels directly)
     uint32_t total_jobs;    // n_blocks * 256
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
 };
@@ -172,7 +174,7 @@ PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t m
 }
 
 // Pixel jobs.  A lane is not tied to one pixel: when its pixel has all its samples it writes the pixel back and
-// claims the next unclaimed one from a launch-wide counter, so that a wave stays full until the frame runs out
+// claims the next unclaimed one (claim_pixel), so that a wave stays full until the frame runs out
 // of pixels, however unequal the pixels are (a Mandelbulb's silhouette costs a hundred times a background
 // pixel).  Job j is pixel (j & 255) of this launch's 16x16 block (j >> 8), 8x8 quadrant by quadrant; all the
 // samples of a pixel are still folded in order by the one lane that owns it, so results do not depend on which
@@ -189,10 +191,35 @@ PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J) {
     return J.tx < P.tile_w && J.ty < P.tile_h;
 }
 // Claims jobs until one lies inside the tile; loads that pixel's accumulator into the lane's LDS slots.
+// With claim_tile == 64 a wave takes jobs from the launch-wide counter 64 at a time (one 8x8 quadrant: one
+// device-scope atomic per 64 pixels) and hands them to its lanes from its own {next, end} pair, which only this
+// wave touches (lanes of a wave never run concurrently with each other, so the pair needs no stronger than
+// workgroup-scope atomics): the lanes of a wave stay on neighbouring pixels, which serves meshes and the Moebius
+// marcher (+4 % / +18 %).  With claim_tile == 1 every lane claims single pixels from the counter: heavy pixels
+// spread over all waves, which serves the fractal scenes (a whole quadrant of silhouette pixels in one wave
+// costs 23 %) and, slightly, the Cornell box.
 PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate, float* px_f, PixelJob& J) {
     uint32_t* px_u = (uint32_t*)px_f;
+    uint2* wt = P.wave_tiles + (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     for (;;) {
-        if (!have_candidate) job = atomicAdd(P.job_counter, 1u);
+        if (!have_candidate && P.claim_tile <= 1u) {
+            job = atomicAdd(P.job_counter, 1u);
+        } else if (!have_candidate) {
+            job = __hip_atomic_fetch_add(&wt->x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t end = __hip_atomic_load(&wt->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (job >= end) {  // the wave's tile is used up: the first of the lanes standing here fetches the next
+                const unsigned long long need = __ballot(true);
+                const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)need) - 1u;
+                uint32_t base = 0u;
+                if (lane == leader) {
+                    base = atomicAdd(P.job_counter, P.claim_tile);
+                    __hip_atomic_store(&wt->y, base + P.claim_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&wt->x, base + (uint32_t)__popcll(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                base = (uint32_t)__shfl((int)base, (int)leader, 64);
+                job = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            }
+        }
         have_candidate = false;
         if (job >= P.total_jobs) return false;
         if (job_pixel(P, job, J)) break;
