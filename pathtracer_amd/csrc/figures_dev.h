@@ -885,6 +885,17 @@ PT_DEV bool intersect_t(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t mar
         default: return false;
     }
 }
+// The plane list after the BVH: every lane tests the same figure, so its type is wave-uniform; a plane (the
+// only infinite figure the reference's loaders produce) skips the 17-way switch.
+template <bool FRAC>
+PT_DEV bool intersect_listed(const Ray& ray, V3 inv_dir, const DPrim& g, uint32_t march_steps, float& t, uint32_t& sub) {
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)g.type) == FIG_PLANE) {
+        sub = 0u;
+        PT_SITE_TYPED(10, FIG_PLANE);
+        return isect_plane<false>(ray, g, t, nullptr, false);
+    }
+    return intersect_t<FRAC>(ray, inv_dir, g, march_steps, t, sub);
+}
 // The closed-form types only (the scheduled kernels run the marchers as separate steps).
 PT_DEV bool intersect_closed(const Ray& ray, V3 inv_dir, const DPrim& g, float& t, uint32_t& sub) {
     sub = 0u;

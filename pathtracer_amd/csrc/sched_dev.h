@@ -322,7 +322,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             const DPrim& g = sc.inf[i];
             float ht;
             uint32_t sub;
-            if (intersect_closed(tv.ray, tv.inv_dir, g, ht, sub) && ht > PT_EPS && ht < tv.bound) {
+            if (intersect_listed<false>(tv.ray, tv.inv_dir, g, 0u, ht, sub) && ht > PT_EPS && ht < tv.bound) {
                 tv.bound = ht;
                 tv.slot = PT_SLOT_INF | i;
                 tv.sub = sub;
@@ -457,7 +457,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             const DPrim& g = sc.inf[i];
             float ht;
             uint32_t sub;
-            if (intersect_closed(tv.ray, tv.inv_dir, g, ht, sub) && ht > PT_EPS && ht < tv.bound - PT_EPS)
+            if (intersect_listed<false>(tv.ray, tv.inv_dir, g, 0u, ht, sub) && ht > PT_EPS && ht < tv.bound - PT_EPS)
                 if (sc.nneg == 0u || !inside_any_negative(sc, madd(tv.ray.o, tv.ray.d, ht))) occluded = true;
         }
         if (!occluded && lit)  // path_trace.wgsl:148: only when light_solid_pdf > 0

@@ -121,7 +121,7 @@ PT_DEV void trace_positive_loop(const DScene& sc, const Ray& ray, V3 inv_dir, ui
         const DPrim& g = sc.inf[i];
         float ht;
         uint32_t sub;
-        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_best) {
+        if (intersect_listed<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_best) {
             t_best = ht;
             slot_best = PT_SLOT_INF | i;
             sub_best = sub;
@@ -199,7 +199,7 @@ PT_DEV void trace_positive_walk(const DScene& sc, const Ray& ray, V3 inv_dir, ui
         const DPrim& g = sc.inf[i];
         float ht;
         uint32_t sub;
-        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_best) {
+        if (intersect_listed<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_best) {
             t_best = ht;
             slot_best = PT_SLOT_INF | i;
             sub_best = sub;
@@ -376,7 +376,7 @@ PT_DEV bool trace_shadow_loop(const DScene& sc, const Ray& ray, float max_t, uin
         const DPrim& g = sc.inf[i];
         float ht;
         uint32_t sub;
-        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
+        if (intersect_listed<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
     }
     return false;
@@ -442,7 +442,7 @@ PT_DEV bool trace_shadow_walk(const DScene& sc, const Ray& ray, float max_t, uin
         const DPrim& g = sc.inf[i];
         float ht;
         uint32_t sub;
-        if (intersect_t<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
+        if (intersect_listed<FRAC>(ray, inv_dir, g, march_steps, ht, sub) && ht > PT_EPS && ht < t_lim)
             if (sc.nneg == 0u || !inside_any_negative(sc, madd(ray.o, ray.d, ht))) return true;
     }
     return false;
