@@ -138,7 +138,6 @@ PT_DEV void trace_body(const TraceParams& P) {
         if (done) {
             PT_SITE(36);
             // path_trace.wgsl:181 and :44-49
-            job_pixel(P, job, J);
             const uint32_t k = px_u[6 * 64];
             V3 mean = v3(px_f[0 * 64], px_f[1 * 64], px_f[2 * 64]);
             V3 rad = v3(dm::fmax_(ps.radiance.x, 0.0f), dm::fmax_(ps.radiance.y, 0.0f), dm::fmax_(ps.radiance.z, 0.0f));
