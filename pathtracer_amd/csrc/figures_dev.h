@@ -36,10 +36,9 @@ PT_DEV V3 onb_mul(const Onb& o, V3 l) {
 template <bool FULL>
 PT_DEV bool isect_sphere(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // sphere.wgsl:4-40
     V3 pos = v3p(g.p);
-    float radius = g.p[3];
     V3 oc = ray.o - pos;
     float half_b = dot(oc, ray.d);
-    float c = dot(oc, oc) - radius * radius;
+    float c = dot(oc, oc) - g.p[4];  // radius * radius, multiplied at upload
     float disc = dm::fma_(half_b, half_b, -c);
     if (disc < 0.0f) return false;
     float sqrtd = dm::sqrt_(disc);
@@ -80,8 +79,7 @@ template <bool FULL>
 PT_DEV bool isect_cube(const Ray& ray, V3 inv_dir, const DPrim& g, float& t_out, HitFull* h) {  // cube.wgsl:4-60
     V3 pos = v3p(g.p);
     float r = g.p[3];
-    V3 half = v3(r, r, r);
-    V3 bmin = pos - half, bmax = pos + half;
+    V3 bmin = v3p(g.p + 4), bmax = v3p(g.p + 7);  // pos -+ (r, r, r), computed at upload
     V3 t1 = (bmin - ray.o) * inv_dir, t2 = (bmax - ray.o) * inv_dir;
     V3 tmn = vmin(t1, t2), tmx = vmax(t1, t2);
     float t_near = dm::fmax_(dm::fmax_(tmn.x, tmn.y), tmn.z);
@@ -237,7 +235,7 @@ PT_DEV bool isect_disc(const Ray& ray, const DPrim& g, float& t_out, HitFull* h)
     if (t < PT_EPS) return false;
     V3 p = madd(ray.o, ray.d, t);
     V3 off = p - pos;
-    if (dot(off, off) > radius * radius) return false;
+    if (dot(off, off) > g.p[7]) return false;  // radius * radius, multiplied at upload
     t_out = t;
     if (FULL) {
         h->pos = p;
@@ -368,9 +366,7 @@ PT_DEV bool isect_tetrahedron(const Ray& ray, const DPrim& g, float& t_out, HitF
 template <bool FULL>
 PT_DEV bool isect_ellipsoid(const Ray& ray, const DPrim& g, float& t_out, HitFull* h, bool need_uv) {  // ellipsoid.wgsl:5-52
     V3 pos = v3p(g.p);
-    float radius = g.p[3], height = g.p[4], radius2 = g.p[5];
-    V3 radii = v3(radius, dm::fmax_(height, radius), dm::fmax_(radius2, radius));
-    V3 inv_radii = vrcp(radii);
+    V3 inv_radii = v3p(g.p + 6);  // 1 / (radius, max(height, radius), max(radius2, radius)), computed at upload
     V3 oc = (ray.o - pos) * inv_radii;
     V3 dir = ray.d * inv_radii;
     float a = dot(dir, dir);
@@ -633,8 +629,7 @@ PT_DEV bool march_torus(const Ray& ray, const DPrim& g, float& t_out) {
     V3 pos = v3p(g.p);
     V3 oc = ray.o - pos;
     float b = dot(oc, ray.d);
-    float br = bound_r + minor_r;
-    float cc = dot(oc, oc) - br * br;
+    float cc = dot(oc, oc) - g.p[5];  // (major + 2 minor)^2, computed at upload
     float disc = dm::fma_(b, b, -cc);
     if (disc < 0.0f) return false;
     const float omega = 1.4f;
@@ -680,8 +675,7 @@ PT_DEV bool march_mebius(const Ray& ray, const DPrim& g, float& t_out) {
     float R = g.p[3];
     V3 oc = ray.o - pos;
     float b = dot(oc, ray.d);
-    float bound_r = R * 1.5f;
-    float cc = dot(oc, oc) - bound_r * bound_r;
+    float cc = dot(oc, oc) - g.p[4];  // (1.5 R)^2, computed at upload
     float disc = dm::fma_(b, b, -cc);
     if (disc < 0.0f) return false;
     float sq = dm::sqrt_(disc);
@@ -714,8 +708,7 @@ PT_DEV bool march_fractal(const Ray& ray, const DPrim& g, uint32_t march_steps, 
     float radius = g.p[3];
     V3 oc = ray.o - pos;
     float b = dot(oc, ray.d);
-    float bound_r = radius * 1.5f;
-    float cs = dot(oc, oc) - bound_r * bound_r;
+    float cs = dot(oc, oc) - g.p[9];  // (1.5 radius)^2, computed at upload
     float disc = dm::fma_(b, b, -cs);
     if (disc < 0.0f) return false;
     const float omega = 1.3f;
@@ -764,8 +757,7 @@ PT_DEV bool march_begin_torus(const Ray& ray, const DPrim& g, MarchState& m) {
     float bound_r = major_r + minor_r;
     V3 oc = ray.o - v3p(g.p);
     float b = dot(oc, ray.d);
-    float br = bound_r + minor_r;
-    float cc = dot(oc, oc) - br * br;
+    float cc = dot(oc, oc) - g.p[5];  // (major + 2 minor)^2, computed at upload
     float disc = dm::fma_(b, b, -cc);
     if (disc < 0.0f) return false;
     float sq = dm::sqrt_(dm::fmax_(disc, 0.0f));
@@ -800,8 +792,7 @@ PT_DEV bool march_begin_mebius(const Ray& ray, const DPrim& g, MarchState& m) {
     float R = g.p[3];
     V3 oc = ray.o - v3p(g.p);
     float b = dot(oc, ray.d);
-    float bound_r = R * 1.5f;
-    float cc = dot(oc, oc) - bound_r * bound_r;
+    float cc = dot(oc, oc) - g.p[4];  // (1.5 R)^2, computed at upload
     float disc = dm::fma_(b, b, -cc);
     if (disc < 0.0f) return false;
     float sq = dm::sqrt_(disc);
@@ -824,8 +815,7 @@ PT_DEV bool march_begin_fractal(const Ray& ray, const DPrim& g, uint32_t march_s
     float radius = g.p[3];
     V3 oc = ray.o - v3p(g.p);
     float b = dot(oc, ray.d);
-    float bound_r = radius * 1.5f;
-    float cs = dot(oc, oc) - bound_r * bound_r;
+    float cs = dot(oc, oc) - g.p[9];  // (1.5 radius)^2, computed at upload
     float disc = dm::fma_(b, b, -cs);
     if (disc < 0.0f) return false;
     float sq = dm::sqrt_(disc);
@@ -989,8 +979,7 @@ PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, uin
         case FIG_JULIA: if (FRAC) finish_fractal(ray, g, t, h); break;
         case FIG_ELLIPSOID: {
             V3 pos = v3p(g.p);
-            float radius = g.p[3], height = g.p[4], radius2 = g.p[5];
-            V3 inv_radii = vrcp(v3(radius, dm::fmax_(height, radius), dm::fmax_(radius2, radius)));
+            V3 inv_radii = v3p(g.p + 6);
             h->pos = madd(ray.o, ray.d, t);
             V3 local = h->pos - pos;
             h->normal = normalize(local * inv_radii * inv_radii);

@@ -512,6 +512,29 @@ int upload_vec(ptx_ctx* c, const std::vector<T>& v, const T** dst) {
 }
 
 // Re-layout of one reference figure (src/scene/shape.rs:223-248) into the 64-byte intersector record.
+// The division contract's reciprocal (dmath_dev.h) for values precomputed on the host.
+float host_rcp(float y) {
+    if (y != y) return y;
+    uint32_t b;
+    memcpy(&b, &y, 4);
+    const uint32_t sign = b & 0x80000000u, inf = sign | 0x7f800000u;
+    float r;
+    if ((b & 0x7f800000u) == 0u) { memcpy(&r, &inf, 4); return r; }
+    volatile float q = 1.0f / y;
+    r = q;
+    memcpy(&b, &r, 4);
+    if ((b & 0x7f800000u) == 0u) memcpy(&r, &sign, 4);
+    return r;
+}
+
+// IEEE maxNum with +0 above -0, as v_max_f32 and the oracle's fmax_.
+float host_fmax(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) { uint32_t u; memcpy(&u, &a, 4); return (u & 0x80000000u) ? b : a; }
+    return a > b ? a : b;
+}
+
 DPrim make_prim(const ptx_shape& f, uint32_t fig) {
     DPrim g;
     memset(&g, 0, sizeof(g));
@@ -520,13 +543,22 @@ DPrim make_prim(const ptx_shape& f, uint32_t fig) {
     float* p = g.p;
     p[0] = f.position[0]; p[1] = f.position[1]; p[2] = f.position[2];
     auto put3 = [&](int at, const float* v) { p[at] = v[0]; p[at + 1] = v[1]; p[at + 2] = v[2]; };
+    // Ray-independent subexpressions are evaluated here once, with the single f32 operations (volatile: no
+    // contraction, no reassociation) the intersectors would otherwise repeat per ray.
+    volatile float a, b;
     switch (f.shape_type) {
-        case FIG_SPHERE: case FIG_CUBE: case FIG_TETRAHEDRON: case FIG_SKYBOX: case FIG_MEBIUS: p[3] = f.radius; break;
+        case FIG_SPHERE: p[3] = f.radius; a = f.radius * f.radius; p[4] = a; break;
+        case FIG_CUBE:
+            p[3] = f.radius;
+            for (int i = 0; i < 3; i++) { a = f.position[i] - f.radius; b = f.position[i] + f.radius; p[4 + i] = a; p[7 + i] = b; }
+            break;
+        case FIG_TETRAHEDRON: case FIG_SKYBOX: p[3] = f.radius; break;
+        case FIG_MEBIUS: p[3] = f.radius; a = f.radius * 1.5f; a = a * a; p[4] = a; break;
         case FIG_PLANE: put3(3, f.normal); break;
-        case FIG_DISC: put3(3, f.normal); p[6] = f.radius; break;
+        case FIG_DISC: put3(3, f.normal); p[6] = f.radius; a = f.radius * f.radius; p[7] = a; break;
         case FIG_CYLINDER: put3(3, f.normal); p[6] = f.radius; p[7] = f.height; break;
         case FIG_CONE: put3(3, f.normal); p[6] = f.radius; p[7] = f.height; p[8] = f.radius2; break;
-        case FIG_TORUS: p[3] = f.radius; p[4] = f.radius2; break;
+        case FIG_TORUS: p[3] = f.radius; p[4] = f.radius2; a = f.radius + f.radius2; a = a + f.radius2; a = a * a; p[5] = a; break;
         case FIG_TRIANGLE: {
             // e1 = v1 - v0, e2 = v2 - v0: the same single f32 subtractions triangle.wgsl:9-10 performs per ray.
             volatile float e[6];
@@ -535,9 +567,12 @@ DPrim make_prim(const ptx_shape& f, uint32_t fig) {
             for (int i = 0; i < 6; i++) p[3 + i] = e[i];
             break;
         }
-        case FIG_MANDELBULB: p[3] = f.radius; p[4] = f.v0[0]; p[5] = f.v0[1]; break;
-        case FIG_JULIA: p[3] = f.radius; p[4] = f.v0[1]; put3(5, f.rotation); p[8] = f.radius2; break;
-        case FIG_ELLIPSOID: p[3] = f.radius; p[4] = f.height; p[5] = f.radius2; break;
+        case FIG_MANDELBULB: p[3] = f.radius; p[4] = f.v0[0]; p[5] = f.v0[1]; a = f.radius * 1.5f; a = a * a; p[9] = a; break;
+        case FIG_JULIA: p[3] = f.radius; p[4] = f.v0[1]; put3(5, f.rotation); p[8] = f.radius2; a = f.radius * 1.5f; a = a * a; p[9] = a; break;
+        case FIG_ELLIPSOID:
+            p[3] = f.radius; p[4] = f.height; p[5] = f.radius2;
+            p[6] = host_rcp(f.radius); p[7] = host_rcp(host_fmax(f.height, f.radius)); p[8] = host_rcp(host_fmax(f.radius2, f.radius));
+            break;
         case FIG_PARABOLOID: case FIG_HYPERBOLOID: case FIG_PYRAMID: p[3] = f.radius; p[4] = f.height; break;
         default: g.type = FIG_SKIP; break;  // unknown type: dispatch.wgsl:78-81 reports no hit
     }
@@ -613,21 +648,6 @@ static bool pick_sched(const DScene& sc, const std::vector<DPrim>& prims) {
     for (const DPrim& g : prims)
         if (g.type == FIG_MEBIUS) return true;
     return false;
-}
-
-// The division contract's reciprocal (dmath_dev.h) for values precomputed on the host.
-static float host_rcp(float y) {
-    if (y != y) return y;
-    uint32_t b;
-    memcpy(&b, &y, 4);
-    const uint32_t sign = b & 0x80000000u, inf = sign | 0x7f800000u;
-    float r;
-    if ((b & 0x7f800000u) == 0u) { memcpy(&r, &inf, 4); return r; }
-    volatile float q = 1.0f / y;
-    r = q;
-    memcpy(&b, &r, 4);
-    if ((b & 0x7f800000u) == 0u) memcpy(&r, &sign, 4);
-    return r;
 }
 
 int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx_material* mats, uint32_t nmat,
