@@ -42,10 +42,16 @@ open('gpurun_out/prof/pmc_summary.txt', 'w').write('\n'.join(lines) + '\n')
 g = {k[1]: v[0] / max(v[1], 1) for k, v in agg.items()}
 if 'FETCH_SIZE' in g and 'WRITE_SIZE' in g:
     # KB per dispatch; FETCH_SIZE is doubled (the counter counts 64 B requests as 32 B on gfx950)
-    json.dump({"workload": "cornell", "spp_per_step": 128, "hbm_bytes_per_launch": int((2 * g['FETCH_SIZE'] + g['WRITE_SIZE']) * 1024),
-               "fetch_size_kb_per_launch_raw": g['FETCH_SIZE'], "write_size_kb_per_launch": g['WRITE_SIZE'],
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 correction)"},
-              open('gpurun_out/prof/traffic.json', 'w'), indent=1)
+    t = {"workload": "cornell", "spp_per_step": 128, "hbm_bytes_per_launch": int((2 * g['FETCH_SIZE'] + g['WRITE_SIZE']) * 1024),
+         "fetch_size_kb_per_launch_raw": g['FETCH_SIZE'], "write_size_kb_per_launch": g['WRITE_SIZE'],
+         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 correction)"}
+    if 'GRBM_GUI_ACTIVE' in g and 'SQ_ACTIVE_INST_VALU' in g:
+        simd_cycles = g['GRBM_GUI_ACTIVE'] / 8 * 1024  # the counter sums 8 XCDs; 256 CUs x 4 SIMDs
+        t["valu_issue"] = {"valu_busy_frac": round(g['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles, 4),
+                           "lane_utilisation": round(g['SQ_THREAD_CYCLES_VALU'] / (g['SQ_ACTIVE_INST_VALU'] * 64), 4),
+                           "valu_wave_instructions_per_launch": g['SQ_INSTS_VALU'],
+                           "note": "SQ_ACTIVE_INST_VALU x 4 cycles over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs; SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)"}
+    json.dump(t, open('gpurun_out/prof/traffic.json', 'w'), indent=1)
 print(open('gpurun_out/prof/kernel_stats_summary.txt').read())
 print('\n'.join(lines))
 PY
