@@ -91,6 +91,11 @@ int pth_accumulator_advance(pth_accumulator* a, uint32_t* frame_for_sample);
 /* buffers::dispatch_size (src/gpu/buffers.rs:64-66): ceil-div used for the reference's 8x8 workgroups. */
 uint32_t pth_dispatch_size(uint32_t extent, uint32_t workgroup);
 
+/* AppState::build_post_params (src/app/state.rs:448-466): the post-process pass's 16-word uniform (the layout of
+ * ptx_post_params): at most 8 effect ids are taken (POST_PARAMS_MAX_EFFECTS, src/constants.rs:64). */
+void pth_build_post_params(uint32_t width, uint32_t height, const uint32_t* effects, uint32_t n_effects, uint32_t oil_radius,
+                           uint32_t comic_levels, uint32_t out_params[16]);
+
 /* f32 -> binary16 bits as the reference packs triangle UVs (src/scene/shape.rs:290-322): truncating. */
 uint16_t pth_f32_to_f16_bits(float v);
 

@@ -61,6 +61,15 @@ typedef struct ptx_bvh_node {
 /* src/io/texture_atlas.rs:10-18.  16 bytes; `offset` counts pixels. */
 typedef struct ptx_texture_info { uint32_t width, height, offset, _pad; } ptx_texture_info;
 
+/* PostParams uniform of the post-process pass, 64 bytes (post_process.wgsl:5-16; built by
+ * AppState::build_post_params, src/app/state.rs:448-466).  effects[i]: 0 none, 1 negative, 2 sepia, 3 grayscale,
+ * 4 fxaa, 5 oil painting, 6 black & white, 7 comic, 8 casting (src/render/post_process.rs:17-30). */
+typedef struct ptx_post_params {
+    uint32_t width, height, effect_count, oil_radius;
+    uint32_t effects[8];
+    uint32_t comic_levels, _pad2, _pad3, _pad4;
+} ptx_post_params;
+
 typedef enum ptx_status {
     PTX_OK = 0,
     PTX_ERR_BAD_ARG = -1,
@@ -135,6 +144,12 @@ int ptx_sync(ptx_ctx* ctx);
 int ptx_read_accum(ptx_ctx* ctx, float* rgba_f32);
 int ptx_read_output(ptx_ctx* ctx, uint8_t* rgba8);
 
+/* The reverse of ptx_read_accum / ptx_read_moments (no reference counterpart; its accumulation buffer only ever
+ * lives on the device): loads w*h*4 floats into the accumulation buffer and, when m2 is not NULL and moments are
+ * enabled, w*h*3 floats into the M2 buffer, to resume a progressive render (continue with first_sample =
+ * samples already in the buffer + 1) or to post-process an image rendered elsewhere. */
+int ptx_write_accum(ptx_ctx* ctx, const float* rgba_f32, const float* m2);
+
 /* Parity hooks (no reference counterpart): figure index hit by the camera ray of the most recent
  * sample of each pixel (0xFFFFFFFF = miss), w*h u32; and per-sample radiance capture for the next
  * traces: ptx_debug_capture(ctx, max_samples) allocates max_samples * tile_w * tile_h * 3 floats
@@ -165,6 +180,13 @@ int ptx_merge_moments(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, uin
  * (apply_tonemap + rgba8unorm store, tonemap.wgsl:27-42, path_trace.wgsl:52-53): for accumulation data
  * that arrived from another GPU. */
 int ptx_tonemap(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, const ptx_camera* cam);
+
+/* The reference's post-process pass (dispatch_post_process, src/render/frame.rs:24-39; post_process.wgsl:88-102):
+ * applies params->effects[0 .. effect_count) in order to every pixel of the accumulation buffer (read as it is,
+ * without tone mapping; the spatial effects read the original buffer) and overwrites the rgba8 output, as the
+ * reference's pass overwrites the output texture after the trace of the same frame.  Asynchronous on the
+ * context's stream.  width / height must equal the frame size, effect_count <= 8. */
+int ptx_post_process(ptx_ctx* ctx, const ptx_post_params* params);
 
 int ptx_read_stats(ptx_ctx* ctx, ptx_stats* out);
 

@@ -146,6 +146,31 @@ def tonemap(cam: np.ndarray, rgb: np.ndarray) -> np.ndarray:
     return out
 
 
+EFFECTS = {"none": 0, "negative": 1, "sepia": 2, "grayscale": 3, "fxaa": 4, "oil": 5, "bw": 6, "comic": 7, "casting": 8}
+
+
+def post_params(width: int, height: int, effects, oil_radius: int = 3, comic_levels: int = 4) -> np.ndarray:
+    """AppState::build_post_params (app/state.rs:448-466): the 16-word uniform of the post-process pass."""
+    p = np.zeros(16, dtype=np.uint32)
+    p[0], p[1] = width, height
+    ids = [EFFECTS[e] if isinstance(e, str) else int(e) for e in effects][:8]
+    p[2], p[3] = len(ids), oil_radius
+    p[4:4 + len(ids)] = ids
+    p[12] = comic_levels
+    return p
+
+
+def post_process(accum: np.ndarray, params: np.ndarray, threads: int = 0) -> np.ndarray:
+    """The reference's post-process pass over an (h, w, 4) f32 accumulation image; returns (h, w, 4) u8."""
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    h, w = accum.shape[:2]
+    params = np.ascontiguousarray(params, dtype=np.uint32)
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    if lib().pto_post_process(_p(accum), C.c_uint32(w), C.c_uint32(h), _p(params), _p(out), C.c_int(threads)) != 0:
+        raise ValueError("post_process: unusable parameters")
+    return out
+
+
 def unpack2x16float(packed_bits: np.ndarray) -> np.ndarray:
     pk = np.ascontiguousarray(packed_bits, dtype=np.uint32)
     out = np.zeros((pk.size, 2), dtype=np.float32)

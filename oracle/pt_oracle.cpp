@@ -1545,4 +1545,115 @@ int pto_max_threads() {
     return 1;
 #endif
 }
+
+// ---- post-process pass (src/shaders/wgsl/post_process.wgsl) ------------------------------------------
+// params = the reference's 16-word uniform (post_process.wgsl:5-16, app/state.rs:448-466): width, height,
+// effect_count, oil_radius, effects[8], comic_levels, 3 pad words.  accum = w*h rgba f32 (the accumulation
+// buffer, read untonemapped exactly as the reference's pass does); out = w*h rgba8 (the output texture).
+// Same numerical contract as the trace: dot = fma chain from the low index, everything else unfused and left
+// to right, vector / scalar = vector * rcp(scalar), a literal divisor C as * (1.0f / C), length = sqrt(dot).
+}  // extern "C"
+namespace {
+struct PostImg { const float* a; i32 w, h; };
+inline V3 pp_read(const PostImg& im, i32 x, i32 y) { return v3(im.a + 4 * ((size_t)y * im.w + x)); }  // :32-35
+inline V3 pp_read_clamped(const PostImg& im, i32 x, i32 y) {                                          // :37-41
+    i32 cx = x < 0 ? 0 : (x > im.w - 1 ? im.w - 1 : x), cy = y < 0 ? 0 : (y > im.h - 1 ? im.h - 1 : y);
+    return pp_read(im, cx, cy);
+}
+inline V3 pp_fxaa(const PostImg& im, i32 x, i32 y) {  // :105-135
+    const V3 lw = v3(0.299f, 0.587f, 0.114f);
+    V3 center = pp_read(im, x, y);
+    float luma_c = dot(center, lw);
+    V3 cn = pp_read_clamped(im, x, y - 1), cw = pp_read_clamped(im, x - 1, y), ce = pp_read_clamped(im, x + 1, y),
+       cs = pp_read_clamped(im, x, y + 1);
+    float luma_n = dot(cn, lw), luma_w = dot(cw, lw), luma_e = dot(ce, lw), luma_s = dot(cs, lw);
+    float range = fmax_(fmax_(luma_n, luma_s), fmax_(luma_w, fmax_(luma_e, luma_c))) -
+                  fmin_(fmin_(luma_n, luma_s), fmin_(luma_w, fmin_(luma_e, luma_c)));
+    if (range < fmax_(0.0312f, luma_c * 0.125f)) return center;
+    float horizontal = fabsf(luma_n + luma_s - 2.0f * luma_c);
+    float vertical = fabsf(luma_w + luma_e - 2.0f * luma_c);
+    if (horizontal > vertical) return (cn + cs + center) * (1.0f / 3.0f);
+    return (cw + ce + center) * (1.0f / 3.0f);
+}
+inline V3 pp_oil(const PostImg& im, i32 x, i32 y, i32 radius) {  // :138-158
+    V3 total = v3(0.0f, 0.0f, 0.0f);
+    i32 count = 0;
+    for (i32 dx = -radius; dx <= radius; dx++)
+        for (i32 dy = -radius; dy <= radius; dy++) {
+            i32 sx = x + dx, sy = y + dy;
+            if (sx >= 0 && sx < im.w && sy >= 0 && sy < im.h) {
+                total = total + pp_read(im, sx, sy);
+                count += 1;
+            }
+        }
+    if (count > 0) return vdivs(total, (float)count);
+    return pp_read(im, x, y);
+}
+inline V3 pp_comic(const PostImg& im, i32 x, i32 y, V3 color, u32 comic_levels) {  // :161-186
+    float levels = (float)comic_levels;
+    V3 q = color * levels + v3(0.5f, 0.5f, 0.5f);
+    V3 quantized = vdivs(v3(floorf(q.x), floorf(q.y), floorf(q.z)), levels);
+    static const float sxk[9] = {-1.0f, 0.0f, 1.0f, -2.0f, 0.0f, 2.0f, -1.0f, 0.0f, 1.0f};
+    static const float syk[9] = {-1.0f, -2.0f, -1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 2.0f, 1.0f};
+    V3 gx = v3(0.0f, 0.0f, 0.0f), gy = v3(0.0f, 0.0f, 0.0f);
+    int ki = 0;
+    for (i32 dy = -1; dy <= 1; dy++)
+        for (i32 dx = -1; dx <= 1; dx++) {
+            V3 sc = pp_read_clamped(im, x + dx, y + dy);
+            gx = gx + sc * sxk[ki];
+            gy = gy + sc * syk[ki];
+            ki++;
+        }
+    float edge = length(gx) + length(gy);
+    float edge_mask = edge > 0.3f ? 0.0f : 1.0f;
+    return quantized * edge_mask;
+}
+inline V3 pp_casting(const PostImg& im, i32 x, i32 y) {  // :189-211
+    static const float k[9] = {-2.0f, -1.0f, 0.0f, -1.0f, 1.0f, 1.0f, 0.0f, 1.0f, 2.0f};
+    V3 r = v3(0.0f, 0.0f, 0.0f);
+    int ki = 0;
+    for (i32 dy = -1; dy <= 1; dy++)
+        for (i32 dx = -1; dx <= 1; dx++) {
+            r = r + pp_read_clamped(im, x + dx, y + dy) * k[ki];
+            ki++;
+        }
+    r = r * 0.5f + v3(0.5f, 0.5f, 0.5f);
+    return v3(clampf(r.x, 0.0f, 1.0f), clampf(r.y, 0.0f, 1.0f), clampf(r.z, 0.0f, 1.0f));
+}
+inline V3 pp_effect(const PostImg& im, V3 color, i32 x, i32 y, u32 effect, const u32* params) {  // :50-86
+    switch (effect) {
+        case 1u: return v3(1.0f, 1.0f, 1.0f) - color;
+        case 2u: {
+            float r = dot(color, v3(0.393f, 0.769f, 0.189f)), g = dot(color, v3(0.349f, 0.686f, 0.168f)),
+                  b = dot(color, v3(0.272f, 0.534f, 0.131f));
+            return v3(clampf(r, 0.0f, 1.0f), clampf(g, 0.0f, 1.0f), clampf(b, 0.0f, 1.0f));
+        }
+        case 3u: { float lum = dot(color, v3(0.2126f, 0.7152f, 0.0722f)); return v3(lum, lum, lum); }
+        case 4u: return pp_fxaa(im, x, y);
+        case 5u: return pp_oil(im, x, y, (i32)params[3]);
+        case 6u: { float lum = dot(color, v3(0.2126f, 0.7152f, 0.0722f)); return lum > 0.5f ? v3(1.0f, 1.0f, 1.0f) : v3(0.0f, 0.0f, 0.0f); }
+        case 7u: return pp_comic(im, x, y, color, params[12]);
+        case 8u: return pp_casting(im, x, y);
+        default: return color;
+    }
+}
+}  // namespace
+extern "C" {
+// Returns 0, or -1 when params are not usable (size mismatch, more than 8 effects).
+int pto_post_process(const float* accum, u32 w, u32 h, const u32* params, uint8_t* out_rgba8, int threads) {
+    if (!accum || !params || !out_rgba8 || params[0] != w || params[1] != h || params[2] > 8u) return -1;
+    PostImg im{accum, (i32)w, (i32)h};
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (i32 y = 0; y < (i32)h; y++)
+        for (i32 x = 0; x < (i32)w; x++) {  // :88-102
+            V3 result = pp_read(im, x, y);
+            for (u32 i = 0; i < params[2]; i++) result = pp_effect(im, result, x, y, params[4 + i], params);
+            size_t o = 4 * ((size_t)y * w + x);
+            out_rgba8[o] = unorm8(result.x); out_rgba8[o + 1] = unorm8(result.y); out_rgba8[o + 2] = unorm8(result.z); out_rgba8[o + 3] = 255;
+        }
+    return 0;
+}
 }

@@ -29,6 +29,7 @@ SYMBOLS = [
     ("ptx_trace_n", C.c_int, [_P, _P, _U, _U, _U]),
     ("ptx_sync", C.c_int, [_P]),
     ("ptx_read_accum", C.c_int, [_P, _P]),
+    ("ptx_write_accum", C.c_int, [_P, _P, _P]),
     ("ptx_read_output", C.c_int, [_P, _P]),
     ("ptx_read_primary_ids", C.c_int, [_P, _P]),
     ("ptx_debug_capture", C.c_int, [_P, _U]),
@@ -39,6 +40,7 @@ SYMBOLS = [
     ("ptx_device_moments", _P, [_P]),
     ("ptx_merge_moments", C.c_int, [_P, _U, _U, _U, _P, _P, _U, _P]),
     ("ptx_tonemap", C.c_int, [_P, _U, _U, _P]),
+    ("ptx_post_process", C.c_int, [_P, _P]),
     ("ptx_read_stats", C.c_int, [_P, C.POINTER(PtxStats)]),
     ("ptx_trace_kernel_name", C.c_char_p, [_P]),
     ("ptx_kernel_time", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U)]),

@@ -947,6 +947,18 @@ int pth_accumulator_advance(pth_accumulator* a, uint32_t* frame_for_sample) {
     a->frame_index += 1;   // rendering.rs:82: wrapping_add(1)
     return needs_clear;
 }
+void pth_build_post_params(uint32_t width, uint32_t height, const uint32_t* effects, uint32_t n_effects, uint32_t oil_radius,
+                           uint32_t comic_levels, uint32_t out_params[16]) {
+    for (int i = 0; i < 16; i++) out_params[i] = 0u;
+    out_params[0] = width;
+    out_params[1] = height;
+    const uint32_t count = n_effects < 8u ? n_effects : 8u;
+    out_params[2] = count;
+    out_params[3] = oil_radius;
+    for (uint32_t i = 0; i < count; i++) out_params[4 + i] = effects[i];
+    out_params[12] = comic_levels;
+}
+
 uint32_t pth_dispatch_size(uint32_t extent, uint32_t workgroup) { return workgroup ? (extent + workgroup - 1) / workgroup : 0; }
 
 }  // extern "C"

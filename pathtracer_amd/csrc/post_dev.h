@@ -1,0 +1,99 @@
+// Post-process pass (src/shaders/wgsl/post_process.wgsl): up to 8 chained effects over the accumulation buffer,
+// written as rgba8.  HBM-bound: 16 B read + 4 B written per pixel; the stencil effects (FXAA cross, 3x3 Sobel
+// and emboss, (2r+1)^2 box of the oil painting) read their neighbourhood from an LDS tile, loaded once per
+// 16x16-pixel workgroup with its halo already clamped to the image edge the way read_pixel_clamped does.
+// Same expression trees as the trace kernels' contract (dmath_dev.h).
+#pragma once
+#include "dmath_dev.h"
+#include "../../include/ptx355.h"
+
+#define PP_TILE 16
+#define PP_MAX_HALO 8  // oil radii beyond this read global memory instead of the tile
+
+struct PostImage {
+    const float4* accum;  // w * h
+    const float4* tile;   // LDS tile of (PP_TILE + 2 halo)^2 texels, or null: read accum
+    int w, h, tx0, ty0, halo;
+};
+// Texel (x, y), -halo <= x - tx0 < PP_TILE + halo when the tile is used; outside the image the nearest edge texel.
+PT_DEV V3 pp_read_clamped(const PostImage& im, int x, int y) {  // post_process.wgsl:37-41
+    float4 a;
+    if (im.tile) {
+        a = im.tile[(y - im.ty0 + im.halo) * (PP_TILE + 2 * im.halo) + (x - im.tx0 + im.halo)];
+    } else {
+        int cx = x < 0 ? 0 : (x > im.w - 1 ? im.w - 1 : x), cy = y < 0 ? 0 : (y > im.h - 1 ? im.h - 1 : y);
+        a = im.accum[(size_t)cy * im.w + cx];
+    }
+    return v3(a.x, a.y, a.z);
+}
+PT_DEV V3 pp_fxaa(const PostImage& im, int x, int y) {  // post_process.wgsl:105-135
+    const V3 lw = v3(0.299f, 0.587f, 0.114f);
+    V3 center = pp_read_clamped(im, x, y);
+    float luma_c = dot(center, lw);
+    V3 cn = pp_read_clamped(im, x, y - 1), cw = pp_read_clamped(im, x - 1, y), ce = pp_read_clamped(im, x + 1, y),
+       cs = pp_read_clamped(im, x, y + 1);
+    float luma_n = dot(cn, lw), luma_w = dot(cw, lw), luma_e = dot(ce, lw), luma_s = dot(cs, lw);
+    float range = dm::fmax_(dm::fmax_(luma_n, luma_s), dm::fmax_(luma_w, dm::fmax_(luma_e, luma_c))) -
+                  dm::fmin_(dm::fmin_(luma_n, luma_s), dm::fmin_(luma_w, dm::fmin_(luma_e, luma_c)));
+    if (range < dm::fmax_(0.0312f, luma_c * 0.125f)) return center;
+    float horizontal = dm::abs_(luma_n + luma_s - 2.0f * luma_c);
+    float vertical = dm::abs_(luma_w + luma_e - 2.0f * luma_c);
+    if (horizontal > vertical) return (cn + cs + center) * (1.0f / 3.0f);
+    return (cw + ce + center) * (1.0f / 3.0f);
+}
+PT_DEV V3 pp_oil(const PostImage& im, int x, int y, int radius) {  // post_process.wgsl:138-158
+    V3 total = v3(0.0f, 0.0f, 0.0f);
+    int count = 0;
+    for (int dx = -radius; dx <= radius; dx++)
+        for (int dy = -radius; dy <= radius; dy++) {
+            int sx = x + dx, sy = y + dy;
+            if (sx >= 0 && sx < im.w && sy >= 0 && sy < im.h) {
+                total = total + pp_read_clamped(im, sx, sy);
+                count += 1;
+            }
+        }
+    if (count > 0) return vdivs(total, (float)count);
+    return pp_read_clamped(im, x, y);
+}
+PT_DEV V3 pp_comic(const PostImage& im, int x, int y, V3 color, uint32_t comic_levels) {  // post_process.wgsl:161-186
+    float levels = (float)comic_levels;
+    V3 q = color * levels + v3(0.5f, 0.5f, 0.5f);
+    V3 quantized = vdivs(v3(__builtin_floorf(q.x), __builtin_floorf(q.y), __builtin_floorf(q.z)), levels);
+    const float sxk[9] = {-1.0f, 0.0f, 1.0f, -2.0f, 0.0f, 2.0f, -1.0f, 0.0f, 1.0f};
+    const float syk[9] = {-1.0f, -2.0f, -1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 2.0f, 1.0f};
+    V3 gx = v3(0.0f, 0.0f, 0.0f), gy = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int ki = 0; ki < 9; ki++) {
+        V3 sc = pp_read_clamped(im, x + ki % 3 - 1, y + ki / 3 - 1);
+        gx = gx + sc * sxk[ki];
+        gy = gy + sc * syk[ki];
+    }
+    float edge = length(gx) + length(gy);
+    float edge_mask = edge > 0.3f ? 0.0f : 1.0f;
+    return quantized * edge_mask;
+}
+PT_DEV V3 pp_casting(const PostImage& im, int x, int y) {  // post_process.wgsl:189-211
+    const float k[9] = {-2.0f, -1.0f, 0.0f, -1.0f, 1.0f, 1.0f, 0.0f, 1.0f, 2.0f};
+    V3 r = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int ki = 0; ki < 9; ki++) r = r + pp_read_clamped(im, x + ki % 3 - 1, y + ki / 3 - 1) * k[ki];
+    r = r * 0.5f + v3(0.5f, 0.5f, 0.5f);
+    return v3(clampf(r.x, 0.0f, 1.0f), clampf(r.y, 0.0f, 1.0f), clampf(r.z, 0.0f, 1.0f));
+}
+PT_DEV V3 pp_effect(const PostImage& im, V3 color, int x, int y, uint32_t effect, const ptx_post_params& pp) {  // :50-86
+    switch (effect) {
+        case 1u: return v3(1.0f, 1.0f, 1.0f) - color;
+        case 2u: {
+            float r = dot(color, v3(0.393f, 0.769f, 0.189f)), g = dot(color, v3(0.349f, 0.686f, 0.168f)),
+                  b = dot(color, v3(0.272f, 0.534f, 0.131f));
+            return v3(clampf(r, 0.0f, 1.0f), clampf(g, 0.0f, 1.0f), clampf(b, 0.0f, 1.0f));
+        }
+        case 3u: { float lum = dot(color, v3(0.2126f, 0.7152f, 0.0722f)); return v3(lum, lum, lum); }
+        case 4u: return pp_fxaa(im, x, y);
+        case 5u: return pp_oil(im, x, y, (int)pp.oil_radius);
+        case 6u: { float lum = dot(color, v3(0.2126f, 0.7152f, 0.0722f)); return lum > 0.5f ? v3(1.0f, 1.0f, 1.0f) : v3(0.0f, 0.0f, 0.0f); }
+        case 7u: return pp_comic(im, x, y, color, pp.comic_levels);
+        case 8u: return pp_casting(im, x, y);
+        default: return color;
+    }
+}

@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include "sched_dev.h"
+#include "post_dev.h"
 
 #define PTX_BLOCK 256
 #define PTX_WAVES_PER_BLOCK 4
@@ -332,6 +333,44 @@ extern "C" __global__ void ptx_tonemap_kernel(const float4* accum, uint32_t* out
     if (i >= n_pixels) return;
     float4 a = accum[(size_t)first + i];
     out_rgba8[(size_t)first + i] = tonemap_rgba8(cam, v3(a.x, a.y, a.z));
+}
+
+// Post-process pass: one 16x16-pixel tile per workgroup.  TILE: the tile and a halo of `halo` texels are staged in
+// LDS (clamped to the image edge) and every effect reads from there; otherwise reads go to the accumulation buffer.
+template <bool TILE>
+PT_DEV void post_body(const float4* accum, uint32_t* out_rgba8, const ptx_post_params pp, int halo) {
+    extern __shared__ float4 pp_tile[];
+    PostImage im;
+    im.accum = accum;
+    im.w = (int)pp.width;
+    im.h = (int)pp.height;
+    im.tx0 = (int)blockIdx.x * PP_TILE;
+    im.ty0 = (int)blockIdx.y * PP_TILE;
+    im.halo = halo;
+    im.tile = nullptr;
+    if (TILE) {
+        const int side = PP_TILE + 2 * halo;
+        for (int i = (int)threadIdx.x; i < side * side; i += PP_TILE * PP_TILE) {
+            int x = im.tx0 - halo + i % side, y = im.ty0 - halo + i / side;
+            int cx = x < 0 ? 0 : (x > im.w - 1 ? im.w - 1 : x), cy = y < 0 ? 0 : (y > im.h - 1 ? im.h - 1 : y);
+            pp_tile[i] = accum[(size_t)cy * im.w + cx];
+        }
+        __syncthreads();
+        im.tile = pp_tile;
+    }
+    const int x = im.tx0 + (int)(threadIdx.x % PP_TILE), y = im.ty0 + (int)(threadIdx.x / PP_TILE);
+    if (x >= im.w || y >= im.h) return;
+    V3 result = pp_read_clamped(im, x, y);  // post_process.wgsl:95-101
+    for (uint32_t i = 0; i < pp.effect_count; i++) result = pp_effect(im, result, x, y, pp.effects[i], pp);
+    out_rgba8[(size_t)y * im.w + x] = unorm8(result.x) | (unorm8(result.y) << 8) | (unorm8(result.z) << 16) | 0xFF000000u;
+}
+extern "C" __global__ void __launch_bounds__(PP_TILE* PP_TILE) ptx_post_kernel_tile(const float4* accum, uint32_t* out_rgba8,
+                                                                                    const ptx_post_params pp, int halo) {
+    post_body<true>(accum, out_rgba8, pp, halo);
+}
+extern "C" __global__ void __launch_bounds__(PP_TILE* PP_TILE) ptx_post_kernel(const float4* accum, uint32_t* out_rgba8,
+                                                                               const ptx_post_params pp, int halo) {
+    post_body<false>(accum, out_rgba8, pp, halo);
 }
 
 extern "C" __global__ void ptx_kat_math_kernel(int op, uint32_t n, const float* a, const float* b, float* out) {
@@ -963,6 +1002,16 @@ static int read_back(ptx_ctx* c, void* dst, const void* src, size_t bytes, const
     return PTX_OK;
 }
 int ptx_read_accum(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->accum : nullptr, c ? (size_t)c->w * c->h * 16 : 0, "ptx_read_accum"); }
+int ptx_write_accum(ptx_ctx* c, const float* rgba, const float* m2) {
+    if (!c || !rgba) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_write_accum before ptx_resize");
+    if (m2 && !c->m2) return fail(c, PTX_ERR_STATE, "ptx_write_accum with moments, but moments are not enabled");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->accum, rgba, (size_t)c->w * c->h * 16, hipMemcpyHostToDevice));
+    if (m2) HIP_TRY(c, hipMemcpy(c->m2, m2, (size_t)c->w * c->h * 12, hipMemcpyHostToDevice));
+    return PTX_OK;
+}
 int ptx_read_output(ptx_ctx* c, uint8_t* o) { return read_back(c, o, c ? c->out : nullptr, c ? (size_t)c->w * c->h * 4 : 0, "ptx_read_output"); }
 int ptx_read_primary_ids(ptx_ctx* c, uint32_t* o) { return read_back(c, o, c ? c->ids : nullptr, c ? (size_t)c->w * c->h * 4 : 0, "ptx_read_primary_ids"); }
 int ptx_read_moments(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->m2 : nullptr, c ? (size_t)c->w * c->h * 12 : 0, "ptx_read_moments"); }
@@ -1038,6 +1087,31 @@ extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
     return 0;
 }
 #endif
+
+int ptx_post_process(ptx_ctx* c, const ptx_post_params* pp) {
+    if (!c || !pp) return PTX_ERR_BAD_ARG;
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_post_process before ptx_resize");
+    if (pp->width != c->w || pp->height != c->h) return fail(c, PTX_ERR_BAD_ARG, "post params width/height differ from the frame size");
+    if (pp->effect_count > 8u) return fail(c, PTX_ERR_BAD_ARG, "more than 8 post effects");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // halo the chain needs: 1 for the 3x3 / cross stencils, oil_radius for the oil painting
+    uint32_t halo = 0;
+    for (uint32_t i = 0; i < pp->effect_count; i++) {
+        const uint32_t e = pp->effects[i];
+        if (e == 4u || e == 7u || e == 8u) halo = halo < 1u ? 1u : halo;
+        if (e == 5u) halo = halo < pp->oil_radius ? pp->oil_radius : halo;
+    }
+    if (halo > 0x3FFFFFFFu) return fail(c, PTX_ERR_BAD_ARG, "oil_radius too large");
+    const dim3 grid((c->w + PP_TILE - 1u) / PP_TILE, (c->h + PP_TILE - 1u) / PP_TILE), block(PP_TILE * PP_TILE);
+    if (halo <= PP_MAX_HALO) {
+        const size_t side = PP_TILE + 2u * halo;
+        hipLaunchKernelGGL(ptx_post_kernel_tile, grid, block, side * side * sizeof(float4), c->stream, c->accum, c->out, *pp, (int)halo);
+    } else {
+        hipLaunchKernelGGL(ptx_post_kernel, grid, block, 0, c->stream, c->accum, c->out, *pp, (int)halo);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
 
 const char* ptx_trace_kernel_name(const ptx_ctx* c) {
     if (!c || !c->have_scene) return "";

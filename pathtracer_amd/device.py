@@ -92,6 +92,14 @@ class PathTracer:
         self._ck(self.lib.ptx_read_accum(self.h, _p(out)), "ptx_read_accum")
         return out
 
+    def write_accum(self, rgba: np.ndarray, m2: Optional[np.ndarray] = None):
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert rgba.shape == (self.height, self.width, 4)
+        if m2 is not None:
+            m2 = np.ascontiguousarray(m2, dtype=np.float32)
+            assert m2.shape == (self.height, self.width, 3)
+        self._ck(self.lib.ptx_write_accum(self.h, _p(rgba), _p(m2) if m2 is not None else None), "ptx_write_accum")
+
     def read_output(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         self._ck(self.lib.ptx_read_output(self.h, _p(out)), "ptx_read_output")
@@ -132,6 +140,12 @@ class PathTracer:
     def tonemap(self, first_pixel: int, n_pixels: int, cam):
         cam = _arr(cam, CAMERA_DT)
         self._ck(self.lib.ptx_tonemap(self.h, first_pixel, n_pixels, _p(cam)), "ptx_tonemap")
+
+    def post_process(self, params):
+        """params: 16 uint32 words (host.build_post_params / ptx_post_params).  Overwrites the rgba8 output."""
+        params = np.ascontiguousarray(params, dtype=np.uint32)
+        assert params.size == 16
+        self._ck(self.lib.ptx_post_process(self.h, _p(params)), "ptx_post_process")
 
     def stats(self) -> dict:
         s = _lib.PtxStats()

@@ -49,6 +49,7 @@ SYMBOLS = [
     ("pth_accumulator_reset", None, [C.POINTER(PthAccumulator)]),
     ("pth_accumulator_advance", C.c_int, [C.POINTER(PthAccumulator), C.POINTER(_U)]),
     ("pth_dispatch_size", _U, [_U, _U]),
+    ("pth_build_post_params", None, [_U, _U, _P, _U, _U, _U, _P]),
     ("pth_f32_to_f16_bits", C.c_uint16, [C.c_float]),
 ]
 _lib = None
@@ -245,16 +246,37 @@ class Accumulator:
         return needs_clear, int(f.value)
 
 
+# PostEffect::as_u32 (src/render/post_process.rs:17-30)
+POST_EFFECTS = {"none": 0, "negative": 1, "sepia": 2, "grayscale": 3, "fxaa": 4, "oil": 5, "bw": 6, "comic": 7, "casting": 8}
+DEFAULT_OIL_RADIUS, DEFAULT_COMIC_LEVELS = 3, 4  # src/constants.rs:28-29
+
+
+def build_post_params(width: int, height: int, effects, oil_radius: int = DEFAULT_OIL_RADIUS,
+                      comic_levels: int = DEFAULT_COMIC_LEVELS) -> np.ndarray:
+    """AppState::build_post_params (src/app/state.rs:448-466): the post-process pass's 16-word uniform."""
+    ids = np.array([POST_EFFECTS[e] if isinstance(e, str) else int(e) for e in effects], dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    load().pth_build_post_params(width, height, ids.ctypes.data_as(_P), len(ids), oil_radius, comic_levels, out.ctypes.data_as(_P))
+    return out
+
+
 class FrameLoop:
-    """The render half of AppState::update_and_render (src/app/rendering.rs:72-120): per frame,
-    accumulator.advance(), camera uniform with (frame_index, sample_count), optional clear, dispatch."""
+    """The render half of AppState::update_and_render (src/app/rendering.rs:72-128): per frame,
+    accumulator.advance(), camera uniform with (frame_index, sample_count), optional clear, dispatch, and the
+    post-process dispatch when effects are active."""
 
     def __init__(self, scene: Scene, tracer, width: int, height: int):
         self.scene, self.tracer = scene, tracer
         self.width, self.height = width, height
         self.acc = Accumulator()
+        self.active_effects = []  # AppState::active_effects
+        self.oil_radius, self.comic_levels = DEFAULT_OIL_RADIUS, DEFAULT_COMIC_LEVELS
         scene.upload_to(tracer)
         tracer.resize(width, height)
+
+    def _post(self):
+        if self.active_effects:  # rendering.rs:122-130
+            self.tracer.post_process(build_post_params(self.width, self.height, self.active_effects, self.oil_radius, self.comic_levels))
 
     def reset(self):
         self.acc.reset()
@@ -265,6 +287,7 @@ class FrameLoop:
         if needs_clear:
             self.tracer.clear()
         self.tracer.trace(cam)
+        self._post()
 
     def render_frames(self, n: int):
         """n frames as one batched launch: identical pixels to n calls of render_frame()."""
@@ -278,3 +301,4 @@ class FrameLoop:
         if needs_clear:
             self.tracer.clear()
         self.tracer.trace_n(cam, frame, first_sample, n)
+        self._post()
