@@ -12,26 +12,28 @@
 
 struct PostImage {
     const float4* accum;  // w * h
-    const float4* tile;   // LDS tile of (PP_TILE + 2 halo)^2 texels, or null: read accum
     int w, h, tx0, ty0, halo;
 };
+extern __shared__ float4 pp_tile[];  // TILE: (PP_TILE + 2 halo)^2 texels around the workgroup's pixels
 // Texel (x, y), -halo <= x - tx0 < PP_TILE + halo when the tile is used; outside the image the nearest edge texel.
+template <bool TILE>
 PT_DEV V3 pp_read_clamped(const PostImage& im, int x, int y) {  // post_process.wgsl:37-41
     float4 a;
-    if (im.tile) {
-        a = im.tile[(y - im.ty0 + im.halo) * (PP_TILE + 2 * im.halo) + (x - im.tx0 + im.halo)];
+    if (TILE) {
+        a = pp_tile[(y - im.ty0 + im.halo) * (PP_TILE + 2 * im.halo) + (x - im.tx0 + im.halo)];
     } else {
         int cx = x < 0 ? 0 : (x > im.w - 1 ? im.w - 1 : x), cy = y < 0 ? 0 : (y > im.h - 1 ? im.h - 1 : y);
         a = im.accum[(size_t)cy * im.w + cx];
     }
     return v3(a.x, a.y, a.z);
 }
+template <bool TILE>
 PT_DEV V3 pp_fxaa(const PostImage& im, int x, int y) {  // post_process.wgsl:105-135
     const V3 lw = v3(0.299f, 0.587f, 0.114f);
-    V3 center = pp_read_clamped(im, x, y);
+    V3 center = pp_read_clamped<TILE>(im, x, y);
     float luma_c = dot(center, lw);
-    V3 cn = pp_read_clamped(im, x, y - 1), cw = pp_read_clamped(im, x - 1, y), ce = pp_read_clamped(im, x + 1, y),
-       cs = pp_read_clamped(im, x, y + 1);
+    V3 cn = pp_read_clamped<TILE>(im, x, y - 1), cw = pp_read_clamped<TILE>(im, x - 1, y), ce = pp_read_clamped<TILE>(im, x + 1, y),
+       cs = pp_read_clamped<TILE>(im, x, y + 1);
     float luma_n = dot(cn, lw), luma_w = dot(cw, lw), luma_e = dot(ce, lw), luma_s = dot(cs, lw);
     float range = dm::fmax_(dm::fmax_(luma_n, luma_s), dm::fmax_(luma_w, dm::fmax_(luma_e, luma_c))) -
                   dm::fmin_(dm::fmin_(luma_n, luma_s), dm::fmin_(luma_w, dm::fmin_(luma_e, luma_c)));
@@ -41,20 +43,20 @@ PT_DEV V3 pp_fxaa(const PostImage& im, int x, int y) {  // post_process.wgsl:105
     if (horizontal > vertical) return (cn + cs + center) * (1.0f / 3.0f);
     return (cw + ce + center) * (1.0f / 3.0f);
 }
+template <bool TILE>
 PT_DEV V3 pp_oil(const PostImage& im, int x, int y, int radius) {  // post_process.wgsl:138-158
+    // The in-image part of the window is a rectangle: loop over it directly (same taps in the same order, dx
+    // outer and dy inner, as the per-tap bounds test of the shader selects).
+    const int dx0 = -radius > -x ? -radius : -x, dx1 = radius < im.w - 1 - x ? radius : im.w - 1 - x;
+    const int dy0 = -radius > -y ? -radius : -y, dy1 = radius < im.h - 1 - y ? radius : im.h - 1 - y;
     V3 total = v3(0.0f, 0.0f, 0.0f);
-    int count = 0;
-    for (int dx = -radius; dx <= radius; dx++)
-        for (int dy = -radius; dy <= radius; dy++) {
-            int sx = x + dx, sy = y + dy;
-            if (sx >= 0 && sx < im.w && sy >= 0 && sy < im.h) {
-                total = total + pp_read_clamped(im, sx, sy);
-                count += 1;
-            }
-        }
+    for (int dx = dx0; dx <= dx1; dx++)
+        for (int dy = dy0; dy <= dy1; dy++) total = total + pp_read_clamped<TILE>(im, x + dx, y + dy);
+    const int count = (dx1 - dx0 + 1) * (dy1 - dy0 + 1);  // > 0: the pixel itself is inside
     if (count > 0) return vdivs(total, (float)count);
-    return pp_read_clamped(im, x, y);
+    return pp_read_clamped<TILE>(im, x, y);
 }
+template <bool TILE>
 PT_DEV V3 pp_comic(const PostImage& im, int x, int y, V3 color, uint32_t comic_levels) {  // post_process.wgsl:161-186
     float levels = (float)comic_levels;
     V3 q = color * levels + v3(0.5f, 0.5f, 0.5f);
@@ -64,7 +66,7 @@ PT_DEV V3 pp_comic(const PostImage& im, int x, int y, V3 color, uint32_t comic_l
     V3 gx = v3(0.0f, 0.0f, 0.0f), gy = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int ki = 0; ki < 9; ki++) {
-        V3 sc = pp_read_clamped(im, x + ki % 3 - 1, y + ki / 3 - 1);
+        V3 sc = pp_read_clamped<TILE>(im, x + ki % 3 - 1, y + ki / 3 - 1);
         gx = gx + sc * sxk[ki];
         gy = gy + sc * syk[ki];
     }
@@ -72,14 +74,16 @@ PT_DEV V3 pp_comic(const PostImage& im, int x, int y, V3 color, uint32_t comic_l
     float edge_mask = edge > 0.3f ? 0.0f : 1.0f;
     return quantized * edge_mask;
 }
+template <bool TILE>
 PT_DEV V3 pp_casting(const PostImage& im, int x, int y) {  // post_process.wgsl:189-211
     const float k[9] = {-2.0f, -1.0f, 0.0f, -1.0f, 1.0f, 1.0f, 0.0f, 1.0f, 2.0f};
     V3 r = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (int ki = 0; ki < 9; ki++) r = r + pp_read_clamped(im, x + ki % 3 - 1, y + ki / 3 - 1) * k[ki];
+    for (int ki = 0; ki < 9; ki++) r = r + pp_read_clamped<TILE>(im, x + ki % 3 - 1, y + ki / 3 - 1) * k[ki];
     r = r * 0.5f + v3(0.5f, 0.5f, 0.5f);
     return v3(clampf(r.x, 0.0f, 1.0f), clampf(r.y, 0.0f, 1.0f), clampf(r.z, 0.0f, 1.0f));
 }
+template <bool TILE>
 PT_DEV V3 pp_effect(const PostImage& im, V3 color, int x, int y, uint32_t effect, const ptx_post_params& pp) {  // :50-86
     switch (effect) {
         case 1u: return v3(1.0f, 1.0f, 1.0f) - color;
@@ -89,11 +93,11 @@ PT_DEV V3 pp_effect(const PostImage& im, V3 color, int x, int y, uint32_t effect
             return v3(clampf(r, 0.0f, 1.0f), clampf(g, 0.0f, 1.0f), clampf(b, 0.0f, 1.0f));
         }
         case 3u: { float lum = dot(color, v3(0.2126f, 0.7152f, 0.0722f)); return v3(lum, lum, lum); }
-        case 4u: return pp_fxaa(im, x, y);
-        case 5u: return pp_oil(im, x, y, (int)pp.oil_radius);
+        case 4u: return pp_fxaa<TILE>(im, x, y);
+        case 5u: return pp_oil<TILE>(im, x, y, (int)pp.oil_radius);
         case 6u: { float lum = dot(color, v3(0.2126f, 0.7152f, 0.0722f)); return lum > 0.5f ? v3(1.0f, 1.0f, 1.0f) : v3(0.0f, 0.0f, 0.0f); }
-        case 7u: return pp_comic(im, x, y, color, pp.comic_levels);
-        case 8u: return pp_casting(im, x, y);
+        case 7u: return pp_comic<TILE>(im, x, y, color, pp.comic_levels);
+        case 8u: return pp_casting<TILE>(im, x, y);
         default: return color;
     }
 }

@@ -339,7 +339,6 @@ extern "C" __global__ void ptx_tonemap_kernel(const float4* accum, uint32_t* out
 // LDS (clamped to the image edge) and every effect reads from there; otherwise reads go to the accumulation buffer.
 template <bool TILE>
 PT_DEV void post_body(const float4* accum, uint32_t* out_rgba8, const ptx_post_params pp, int halo) {
-    extern __shared__ float4 pp_tile[];
     PostImage im;
     im.accum = accum;
     im.w = (int)pp.width;
@@ -347,7 +346,6 @@ PT_DEV void post_body(const float4* accum, uint32_t* out_rgba8, const ptx_post_p
     im.tx0 = (int)blockIdx.x * PP_TILE;
     im.ty0 = (int)blockIdx.y * PP_TILE;
     im.halo = halo;
-    im.tile = nullptr;
     if (TILE) {
         const int side = PP_TILE + 2 * halo;
         for (int i = (int)threadIdx.x; i < side * side; i += PP_TILE * PP_TILE) {
@@ -356,12 +354,11 @@ PT_DEV void post_body(const float4* accum, uint32_t* out_rgba8, const ptx_post_p
             pp_tile[i] = accum[(size_t)cy * im.w + cx];
         }
         __syncthreads();
-        im.tile = pp_tile;
     }
     const int x = im.tx0 + (int)(threadIdx.x % PP_TILE), y = im.ty0 + (int)(threadIdx.x / PP_TILE);
     if (x >= im.w || y >= im.h) return;
-    V3 result = pp_read_clamped(im, x, y);  // post_process.wgsl:95-101
-    for (uint32_t i = 0; i < pp.effect_count; i++) result = pp_effect(im, result, x, y, pp.effects[i], pp);
+    V3 result = pp_read_clamped<TILE>(im, x, y);  // post_process.wgsl:95-101
+    for (uint32_t i = 0; i < pp.effect_count; i++) result = pp_effect<TILE>(im, result, x, y, pp.effects[i], pp);
     out_rgba8[(size_t)y * im.w + x] = unorm8(result.x) | (unorm8(result.y) << 8) | (unorm8(result.z) << 16) | 0xFF000000u;
 }
 extern "C" __global__ void __launch_bounds__(PP_TILE* PP_TILE) ptx_post_kernel_tile(const float4* accum, uint32_t* out_rgba8,
