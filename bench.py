@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--workload", default="cornell", choices=list(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=0)
     ap.add_argument("--mesh-quads", type=int, default=2236, help="all_mesh: quads per side (2236 -> 10.0 M triangles)")
+    ap.add_argument("--partition", default="", choices=["", "samples", "tiles"],
+                    help="N > 1: sample split (weak scaling, default) or interleaved 16x16 tiles (strong scaling, default for teapot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -73,11 +75,17 @@ def main():
     from pathtracer_amd.device import PathTracer
 
     dist = None
+    # PTX355_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs).
+    backend = os.environ.get("PTX355_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    device = torch.device(f"cuda:{local_rank}")
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    device = torch.device(f"cuda:{dev_index}")
 
     fx_name, w, h, spp_default, label = WORKLOADS[args.workload]
     spp = args.spp_per_step or spp_default
@@ -87,13 +95,17 @@ def main():
     t0 = time.perf_counter()
     scene.build(decode_textures=False)
     build_s = time.perf_counter() - t0
-    pt = PathTracer(local_rank)
+    pt = PathTracer(dev_index)
     t0 = time.perf_counter()
     scene.upload_to(pt)
     upload_s = time.perf_counter() - t0
-    if world > 1:
+    partition = args.partition or ("tiles" if args.workload == "teapot" else "samples")
+    tiles = world > 1 and partition == "tiles"
+    if world > 1 and not tiles:
         pt.enable_moments(True)
     pt.resize(w, h)
+    if tiles:
+        pt.set_partition(rank, world)  # this rank's interleaved 16x16 blocks; every rank traces the same frames
     cam = scene.camera(w, h)
 
     def barrier():
@@ -103,10 +115,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # frame ranges: rank r owns frames [r * steps * spp, (r + 1) * steps * spp), samples counted locally
-    frame0 = rank * (args.steps + args.warmup) * spp
+    # sample split: rank r owns frames [r * steps * spp, (r + 1) * steps * spp), samples counted locally
+    frame0 = 0 if tiles else rank * (args.steps + args.warmup) * spp
     for i in range(args.warmup):
         pt.trace_n(cam, frame0 + i * spp, 1 + i * spp, spp)
+    if dist is not None and args.warmup > 0:
+        # the first collectives set up RCCL's channels: keep that out of the timed region
+        if tiles:
+            multigpu.assemble_tiles(pt, dist, device, cam)
+        else:
+            multigpu.merge_sample_split(pt, dist, device, [args.warmup * spp] * world, cam)
     pt.sync()
     pt.clear()
     pt.kernel_time()
@@ -115,7 +133,10 @@ def main():
     for i in range(args.steps):
         pt.trace_n(cam, frame0 + (args.warmup + i) * spp, 1 + i * spp, spp)
     if dist is not None:
-        multigpu.merge_sample_split(pt, dist, device, [args.steps * spp] * world, cam)
+        if tiles:
+            multigpu.assemble_tiles(pt, dist, device, cam)
+        else:
+            multigpu.merge_sample_split(pt, dist, device, [args.steps * spp] * world, cam)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -124,8 +145,7 @@ def main():
         elapsed = float(t.item())
     kernel_ms, launches = pt.kernel_time()
     st = pt.stats()
-    paths_per_gpu = w * h * spp * args.steps
-    total_paths = paths_per_gpu * world
+    total_paths = w * h * spp * args.steps * (1 if tiles else world)  # tiles: the ranks share one frame
     bounces = st["bounces"]
     if dist is not None:
         t = torch.tensor([bounces], dtype=torch.float64, device=device)
@@ -139,9 +159,10 @@ def main():
             "metric": "Mpaths/s at 1080p (1/2/4/8 GPUs) + % FP32 VALU peak; image RMSE vs ref",
             "value": round(total_paths / elapsed / 1e6, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": w, "height": h, "spp_per_step": spp, "frames": args.steps * spp,
-                       "partition": "single GPU" if world == 1 else f"sample split over {world} GPUs + RCCL Chan merge",
+                       "partition": "single GPU" if world == 1 else (f"interleaved 16x16 tiles over {world} GPUs + RCCL sum" if tiles
+                                                                       else f"sample split over {world} GPUs + RCCL Chan merge"),
                        "scene_build_s": round(build_s, 3), "scene_upload_s": round(upload_s, 3)},
             "gpath_bounce_per_s": round(total_bounces / elapsed / 1e9, 4),
             "bounces_per_path": round(bounces / max(st["paths"], 1), 4),
