@@ -271,7 +271,7 @@ PT_DEV void sched_body(const TraceParams& P) {
         else if (march_n * P.share_march >= live) pick = march;
         if (pick == LS_WALK) {
             for (;;) {
-                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps);
+                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, P.walk_single != 0u);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
                 if (w == 0u || w * P.share_walk < live) break;
             }
@@ -959,6 +959,7 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
+        P.walk_single = c->sc.stack_entries >= 20u ? 1u : 0u;  // trees deeper than ~20 levels (millions of primitives)
         HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
     }
     if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
