@@ -533,18 +533,27 @@ PT_DEV bool sample_brdf(uint32_t& rng, V3 wo, V3 n, const MatD& mat, V3& wi_out,
     float sp, cp;
     dm::sincos_(phi, &sp, &cp);
     Onb onb = build_onb(n);
-    if (pick < spec_prob) {
-        float a2 = alpha * alpha;  // materials.wgsl:38-49
-        float cos_theta = dm::sqrt_(dm::div_(1.0f - ry, 1.0f + (a2 - 1.0f) * ry));
-        float sin_theta = dm::sqrt_(1.0f - cos_theta * cos_theta);
-        h = normalize(onb_mul(onb, v3(sin_theta * cp, sin_theta * sp, cos_theta)));
+    // Both lobes (materials.wgsl:38-49 GGX half vector, utils.wgsl:16-25 cosine hemisphere) build a unit vector
+    // from (sin t cos p, sin t sin p, cos t) in the frame of n; only cos t and sin t differ.  A wave usually holds
+    // lanes of both lobes, so the shared part is written once instead of once per branch (same operations on the
+    // same operands per lane).
+    const bool spec = pick < spec_prob;
+    float cos_arg = ry, sin_arg = 1.0f - ry;
+    if (spec) {
+        float a2 = alpha * alpha;
+        cos_arg = dm::div_(1.0f - ry, 1.0f + (a2 - 1.0f) * ry);
+    }
+    float cos_theta = dm::sqrt_(cos_arg);
+    if (spec) sin_arg = 1.0f - cos_theta * cos_theta;
+    float sin_theta = dm::sqrt_(sin_arg);
+    V3 dir = normalize(onb_mul(onb, v3(sin_theta * cp, sin_theta * sp, cos_theta)));
+    if (spec) {
+        h = dir;
         wi = reflect_vec(-wo, h);
         n_dot_l = dot(n, wi);
         if (n_dot_l <= 0.0f) return false;
     } else {
-        float cos_theta = dm::sqrt_(ry);  // utils.wgsl:16-25
-        float sin_theta = dm::sqrt_(1.0f - ry);
-        wi = normalize(onb_mul(onb, v3(cp * sin_theta, sp * sin_theta, cos_theta)));
+        wi = dir;
         n_dot_l = dm::fmax_(dot(n, wi), 0.0f);
         if (n_dot_l <= 0.0f) return false;
         h = normalize(wo + wi);
