@@ -928,6 +928,7 @@ PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, uin
     uint32_t s2;
     h->uv.x = 0.0f;
     h->uv.y = 0.0f;
+    h->pos = madd(ray.o, ray.d, t);  // every figure's hit position; written once ahead of the divergent switch
     switch (g.type) {
         case FIG_SPHERE: {
             V3 pos = v3p(g.p);
@@ -949,7 +950,20 @@ PT_DEV void resolve_hit(const Ray& ray, V3 inv_dir, const DPrim& g, float t, uin
             }
             break;
         }
-        case FIG_CUBE: isect_cube<true>(ray, inv_dir, g, tt, h); break;
+        case FIG_CUBE: {  // cube.wgsl:28-58 from the known distance
+            V3 pos = v3p(g.p);
+            V3 p = vdivs(h->pos - pos, g.p[3]);
+            V3 ap = vabs(p);
+            if (ap.x > ap.y && ap.x > ap.z) h->normal = v3(signf(p.x), 0.0f, 0.0f);
+            else if (ap.y > ap.z) h->normal = v3(0.0f, signf(p.y), 0.0f);
+            else h->normal = v3(0.0f, 0.0f, signf(p.z));
+            if (need_uv) {
+                if (dm::abs_(h->normal.x) > 0.5f) { h->uv.x = (p.y + 1.0f) * 0.5f; h->uv.y = (p.z + 1.0f) * 0.5f; }
+                else if (dm::abs_(h->normal.y) > 0.5f) { h->uv.x = (p.x + 1.0f) * 0.5f; h->uv.y = (p.z + 1.0f) * 0.5f; }
+                else { h->uv.x = (p.x + 1.0f) * 0.5f; h->uv.y = (p.y + 1.0f) * 0.5f; }
+            }
+            break;
+        }
         case FIG_CYLINDER: isect_cylinder<true>(ray, g, tt, h, need_uv); break;
         case FIG_CONE: isect_cone<true>(ray, g, tt, h, need_uv); break;
         case FIG_TORUS: finish_torus(ray, g, t, h, need_uv); break;
