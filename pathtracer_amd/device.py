@@ -37,6 +37,7 @@ class PathTracer:
         self.device = device
         self.width = self.height = 0
         self.tile = (0, 0, 0, 0)
+        self.moments_enabled = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -120,6 +121,7 @@ class PathTracer:
 
     def enable_moments(self, on: bool = True):
         self._ck(self.lib.ptx_enable_moments(self.h, 1 if on else 0), "ptx_enable_moments")
+        self.moments_enabled = bool(on)
 
     def read_moments(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 3), dtype=np.float32)

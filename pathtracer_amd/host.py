@@ -260,6 +260,27 @@ def build_post_params(width: int, height: int, effects, oil_radius: int = DEFAUL
     return out
 
 
+def save_checkpoint(path: str, tracer, samples: int, frame_index: int):
+    """Progressive-render checkpoint (no reference counterpart: its accumulation lives only on the GPU): the
+    per-pixel count / mean / M2 moments as a plain .npz (no pickling), enough to resume bit-exactly with
+    load_checkpoint and trace_n(cam, frame_index, samples + 1, more)."""
+    tracer.sync()
+    m2 = tracer.read_moments() if tracer.moments_enabled else np.zeros((0,), dtype=np.float32)
+    np.savez_compressed(path, accum=tracer.read_accum(), m2=m2, samples=np.uint32(samples), frame_index=np.uint32(frame_index),
+                        size=np.array([tracer.width, tracer.height], dtype=np.uint32))
+
+
+def load_checkpoint(path: str, tracer):
+    """Loads a save_checkpoint file into a tracer that already has its scene; returns (samples, frame_index)."""
+    d = np.load(path, allow_pickle=False)
+    w, h = (int(v) for v in d["size"])
+    has_m2 = d["m2"].size > 0
+    tracer.enable_moments(has_m2)
+    tracer.resize(w, h)
+    tracer.write_accum(d["accum"], d["m2"] if has_m2 else None)
+    return int(d["samples"]), int(d["frame_index"])
+
+
 class FrameLoop:
     """The render half of AppState::update_and_render (src/app/rendering.rs:72-128): per frame,
     accumulator.advance(), camera uniform with (frame_index, sample_count), optional clear, dispatch, and the

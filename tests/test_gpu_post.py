@@ -123,3 +123,28 @@ def test_resume_from_written_accumulation(pt):
     pt.trace_n(cam, 3, 4, 4)
     assert same_bits(pt.read_accum(), whole) == 0 and same_bits(pt.read_moments(), whole_m2) == 0
     pt.enable_moments(False)
+
+
+def test_checkpoint_file_resumes_bit_exactly(pt, tmp_path):
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    sc.upload_to(pt)
+    w, h = 64, 40
+    cam = sc.camera(w, h)
+    pt.enable_moments(True)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, 6)
+    whole, whole_m2 = pt.read_accum(), pt.read_moments()
+    pt.clear()
+    pt.trace_n(cam, 0, 1, 2)
+    ck = str(tmp_path / "render.npz")
+    host.save_checkpoint(ck, pt, samples=2, frame_index=2)
+    other = PathTracer(0)  # a fresh context, as after a restart
+    try:
+        sc.upload_to(other)
+        samples, frame = host.load_checkpoint(ck, other)
+        assert (samples, frame) == (2, 2) and (other.width, other.height) == (w, h)
+        other.trace_n(cam, frame, samples + 1, 4)
+        assert same_bits(other.read_accum(), whole) == 0 and same_bits(other.read_moments(), whole_m2) == 0
+    finally:
+        other.close()
+    pt.enable_moments(False)
