@@ -36,10 +36,20 @@ static __device__ __noinline__ void pt_site_typed(int base, uint32_t type) {
         }
     }
 }
+static __device__ __noinline__ void pt_site_hist(int base, uint32_t n) {  // histogram of a wave-uniform count 1..64, 8 buckets
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+        int b = base + (int)((n - 1u) >> 3);
+        atomicAdd(&pt_sites[2 * b], 1ull);
+        atomicAdd(&pt_sites[2 * b + 1], (unsigned long long)n);
+    }
+}
 #define PT_SITE(i) pt_site(i)
+#define PT_SITE_HIST(b, n) pt_site_hist(b, n)
 #define PT_SITE_TYPED(b, t) pt_site_typed(b, t)
 #else
 #define PT_SITE(i)
+#define PT_SITE_HIST(b, n)
 #define PT_SITE_TYPED(b, t)
 #endif
 

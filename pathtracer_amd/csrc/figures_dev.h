@@ -560,6 +560,7 @@ PT_DEV float sdf_mandelbulb(V3 p, float power, int max_iter) {  // mandelbulb.wg
     float m = dot(w, w);
     float dz = 1.0f;
     for (int i = 0; i < max_iter; i++) {
+        PT_SITE(44);
         dz = dm::fma_(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
         float r = dm::sqrt_(m);
         float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
@@ -589,6 +590,7 @@ PT_DEV float sdf_julia(V3 p, V4 cc, int max_iter) {  // julia.wgsl:13-32
     float r2 = dot4(z, z);
     for (int i = 0; i < max_iter; i++) {
         if (r2 > 16.0f) break;
+        PT_SITE(45);
         V4 q = quat_mult(z, dz);
         dz.x = 2.0f * q.x; dz.y = 2.0f * q.y; dz.z = 2.0f * q.z; dz.w = 2.0f * q.w;
         V4 zz = quat_mult(z, z);
@@ -846,6 +848,91 @@ PT_DEV int march_step_fractal(const Ray& ray, const DPrim& g, uint32_t march_ste
     }
     m.i += 1u;
     return m.i < march_steps ? MARCH_GO : MARCH_MISS;
+}
+
+// ---- the fractal distance estimators as resumable iterations ---------------------------------------------
+// A Mandelbulb iteration is ~170 instructions (two pow, acos, atan2, two sincos) and points escape after anything
+// from 1 to max_iter of them, so in a wave that evaluates the estimator for many lanes at once most iterations
+// run for a handful of lanes (measured: 6 of 64).  The scheduled kernels therefore run ONE iteration per step for
+// all lanes that are inside either estimator, whatever it is evaluated for (a marching step, the second
+// evaluation of an over-relaxed step, one of the four evaluations of the normal).  frac_eval_begin is the code
+// before the loop of sdf_mandelbulb / sdf_julia, frac_eval_iter one loop iteration and, when the loop is over,
+// the code after it; same operations, same order.
+struct FracIter {
+    float s[9];   // Mandelbulb: w xyz, m, dz, p xyz.  Julia: z xyzw, dz xyzw, r2.
+    uint32_t i;   // iterations done
+};
+PT_DEV void frac_eval_begin(const DPrim& g, V3 p, FracIter& f) {
+    f.i = 0u;
+    if (g.type == FIG_MANDELBULB) {
+        f.s[0] = p.x; f.s[1] = p.y; f.s[2] = p.z;
+        f.s[3] = dot(p, p);
+        f.s[4] = 1.0f;
+        f.s[5] = p.x; f.s[6] = p.y; f.s[7] = p.z;
+        f.s[8] = 0.0f;
+    } else {
+        V4 z; z.x = p.x; z.y = p.y; z.z = p.z; z.w = 0.0f;
+        f.s[0] = z.x; f.s[1] = z.y; f.s[2] = z.z; f.s[3] = z.w;
+        f.s[4] = 1.0f; f.s[5] = 0.0f; f.s[6] = 0.0f; f.s[7] = 0.0f;
+        f.s[8] = dot4(z, z);
+    }
+}
+// Returns true, with the estimator's value, when the evaluation is complete.
+PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value) {
+    if (g.type == FIG_MANDELBULB) {  // mandelbulb.wgsl:5-30
+        const float power = g.p[4];
+        const uint32_t max_iter = (uint32_t)(int)g.p[5];
+        float m = f.s[3], dz = f.s[4];
+        bool done = (int)g.p[5] <= 0 || f.i >= max_iter;
+        if (!done) {
+            PT_SITE(44);
+            V3 w = v3(f.s[0], f.s[1], f.s[2]), p = v3(f.s[5], f.s[6], f.s[7]);
+            dz = dm::fma_(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
+            float r = dm::sqrt_(m);
+            float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
+            float a = power * dm::atan2_(w.x, w.z);
+            float rp = dm::pow_(r, power);
+            float sb, cb, sa, ca;
+            dm::sincos_(b, &sb, &cb);
+            dm::sincos_(a, &sa, &ca);
+            w = p + v3(sb * sa, cb, sb * ca) * rp;
+            m = dot(w, w);
+            f.s[0] = w.x; f.s[1] = w.y; f.s[2] = w.z;
+            f.s[3] = m;
+            f.s[4] = dz;
+            f.i += 1u;
+            done = m > 256.0f || f.i >= max_iter;
+        }
+        if (!done) return false;
+        float r = dm::sqrt_(m);
+        value = dm::div_(0.25f * dm::log_(m) * r, dz);
+        return true;
+    }
+    // julia.wgsl:13-32
+    const uint32_t max_iter = (uint32_t)(int)g.p[4];
+    V4 z; z.x = f.s[0]; z.y = f.s[1]; z.z = f.s[2]; z.w = f.s[3];
+    V4 dz; dz.x = f.s[4]; dz.y = f.s[5]; dz.z = f.s[6]; dz.w = f.s[7];
+    float r2 = f.s[8];
+    bool done = (int)g.p[4] <= 0 || f.i >= max_iter || r2 > 16.0f;
+    if (!done) {
+        PT_SITE(45);
+        V4 cc; cc.x = g.p[5]; cc.y = g.p[6]; cc.z = g.p[7]; cc.w = g.p[8];
+        V4 q = quat_mult(z, dz);
+        dz.x = 2.0f * q.x; dz.y = 2.0f * q.y; dz.z = 2.0f * q.z; dz.w = 2.0f * q.w;
+        V4 zz = quat_mult(z, z);
+        z.x = zz.x + cc.x; z.y = zz.y + cc.y; z.z = zz.z + cc.z; z.w = zz.w + cc.w;
+        r2 = dot4(z, z);
+        f.s[0] = z.x; f.s[1] = z.y; f.s[2] = z.z; f.s[3] = z.w;
+        f.s[4] = dz.x; f.s[5] = dz.y; f.s[6] = dz.z; f.s[7] = dz.w;
+        f.s[8] = r2;
+        f.i += 1u;
+        done = f.i >= max_iter || r2 > 16.0f;
+    }
+    if (!done) return false;
+    float r = dm::sqrt_(r2);
+    float dr = dm::sqrt_(dot4(dz, dz));
+    value = dm::div_(0.5f * r * dm::log_(r), dr);
+    return true;
 }
 
 // Candidate test: hit distance only (figures/dispatch.wgsl:22-89).

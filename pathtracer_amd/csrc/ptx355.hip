@@ -205,10 +205,11 @@ PT_DEV void sched_body(const TraceParams& P) {
     st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
     st.glb = P.stack_spill ? P.stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
     st.nl = P.sc.lds_stack_entries;
+    constexpr uint32_t kFields = SC_PIXEL_FIELDS + SC_PARK_FIELDS + (FRAC ? SC_FRAC_FIELDS : 0u);  // per-lane LDS slots
     float* fields = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u);
     DScene sc = P.sc;
     if (LDS_SCENE) {
-        char* base = (char*)(fields + (size_t)PTX_WAVES_PER_BLOCK * (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u);
+        char* base = (char*)(fields + (size_t)PTX_WAVES_PER_BLOCK * kFields * 64u);
         uint32_t off = 0;
         auto stage = [&](const void* src, uint32_t bytes) -> void* {
             void* dst = base + off;
@@ -224,9 +225,10 @@ PT_DEV void sched_body(const TraceParams& P) {
         sc.negs = (const DNeg*)stage(P.sc.negs, P.sc.nneg * (uint32_t)sizeof(DNeg));
         __syncthreads();
     }
-    float* px_f = fields + (size_t)wave * (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u + lane;
+    float* px_f = fields + (size_t)wave * kFields * 64u + lane;
     uint32_t* px_u = (uint32_t*)px_f;
     float* park = px_f + SC_PIXEL_FIELDS * 64u;
+    float* frac = park + SC_PARK_FIELDS * 64u;  // FRAC kernels only
     px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
     px_u[6 * 64] = 0u;  // samples of the current pixel finished
     px_u[7 * 64] = 0u;  // path-bounces, all pixels of this lane
@@ -271,16 +273,19 @@ PT_DEV void sched_body(const TraceParams& P) {
         else if (march_n * P.share_march >= live) pick = march;
         if (pick == LS_WALK) {
             for (;;) {
-                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, P.walk_single != 0u);
+                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, P.walk_single != 0u, frac);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
                 if (w == 0u || w * P.share_walk < live) break;
             }
         } else if (pick == LS_POST) {
-            if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, px_f, job, n_shadow);
+            if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow);
         } else {
             const uint32_t n0 = pop[pick];
             for (;;) {
-                if (S == pick) S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps);
+                PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(S == pick)));
+                PT_SITE_HIST(60, live);
+                if (S == pick) S = (FRAC && pick >= (uint32_t)LS_MANDEL) ? frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park)
+                                                                        : march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps);
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
                 if (m == 0u || m * 4u < n0 * 3u) break;
             }
@@ -476,6 +481,9 @@ struct ptx_ctx {
     uint32_t shares[3] = {4u, 2u, 4u};  // their scheduling shares (walk, post, march)
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
+    const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
+    size_t occ_lds = 0;
+    int occ_per_cu = 0;
     uint2* wave_tiles = nullptr;  // claim state of every wave of the largest grid so far
     size_t wave_tiles_n = 0;
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
@@ -941,10 +949,30 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;
     P.stats = c->stats;
     size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.lds_stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
-    // The scheduled kernels run a grid sized to the GPU (4 workgroups per compute unit fit at most) whose lanes
-    // claim pixels from a counter that starts behind the grid's own first jobs.
+    const bool frac = c->sc.has_fractals != 0u;
+    const size_t lds_all = lds + c->sc.lds_scene_bytes +  // lds_scene_bytes is 0 for the global-memory kernels
+                           (c->sched && frac ? (size_t)PTX_WAVES_PER_BLOCK * 64u * SC_FRAC_FIELDS * 4u : 0u);
+    void (*kernel)(const TraceParams) =
+        c->sched ? (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_sched_kernel_lds_frac : ptx_sched_kernel_lds) : (frac ? ptx_sched_kernel_frac : ptx_sched_kernel))
+                 : (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_trace_kernel_lds_frac : ptx_trace_kernel_lds) : (frac ? ptx_trace_kernel_frac : ptx_trace_kernel));
+    // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
+    // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
+    // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
     const bool claim = c->sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u);
-    const uint32_t grid = claim ? (P.n_blocks < c->n_cu * 4u ? P.n_blocks : c->n_cu * 4u) : P.n_blocks;
+    uint32_t grid = P.n_blocks;
+    if (claim) {
+        if (c->occ_kernel != (const void*)kernel || c->occ_lds != lds_all) {
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_per_cu, kernel, (int)PTX_BLOCK, lds_all));
+            c->occ_kernel = (const void*)kernel;
+            c->occ_lds = lds_all;
+            if (getenv("PTX355_VERBOSE")) fprintf(stderr, "ptx355: %d workgroups per compute unit, %zu B LDS each\n", c->occ_per_cu, lds_all);
+        }
+        int per_cu = c->occ_per_cu;
+        if (per_cu < 1) return fail(c, PTX_ERR_STATE, "the trace kernel does not fit a compute unit with this scene's LDS size");
+        if (const char* e = getenv("PTX355_GRID_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
+        const uint32_t resident = c->n_cu * (uint32_t)per_cu;
+        grid = P.n_blocks < resident ? P.n_blocks : resident;
+    }
     { int rc = ensure_spill(c, (size_t)grid * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
     if (claim) {
         const size_t waves = (size_t)grid * PTX_WAVES_PER_BLOCK;
@@ -967,11 +995,6 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     int rc;
     if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    const bool frac = c->sc.has_fractals != 0u;
-    const size_t lds_all = lds + c->sc.lds_scene_bytes;  // lds_scene_bytes is 0 for the global-memory kernels
-    void (*kernel)(const TraceParams) =
-        c->sched ? (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_sched_kernel_lds_frac : ptx_sched_kernel_lds) : (frac ? ptx_sched_kernel_frac : ptx_sched_kernel))
-                 : (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_trace_kernel_lds_frac : ptx_trace_kernel_lds) : (frac ? ptx_trace_kernel_frac : ptx_trace_kernel));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(e1, c->stream));

@@ -48,9 +48,16 @@ enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS
 #define SC_PARK_FIELDS 24u   // below
 enum : uint32_t {
     PK_HPOS = 0, PK_N = 3, PK_BASE = 6, PK_FIG = 9, PK_CONTRIB = 10,  // inputs of the BSDF step, parked across the occlusion query
-    PK_THR = 13, PK_RAD = 16, PK_RNG = 19, PK_MISC = 20,              // path state; MISC = bounce | csg attempt << 24 | lit << 31
+    PK_THR = 13, PK_RAD = 16, PK_RNG = 19, PK_MISC = 20,              // path state; MISC = bounce | csg attempt << 24 | normal ready << 28 | lit << 31
     PK_WO = 21
 };
+// Kernels with the fractal code: the estimator's iteration state (FracIter) follows the parked fields.
+#define SC_FRAC_FIELDS 10u   // FracIter::s[0..8], iterations done | phase << 16
+enum : uint32_t { FR_S = 0, FR_I = 9 };
+// What a fractal evaluation is for: a marching step, the second evaluation of an over-relaxed step, or one of
+// the four evaluations of the winner's normal (torus.wgsl:54-61 pattern in mandelbulb.wgsl:83-93 / julia.wgsl:83-93).
+enum : uint32_t { FP_D = 0, FP_D2 = 1, FP_N0 = 2, FP_N1 = 3, FP_N2 = 4, FP_N3 = 5 };
+#define PK_MISC_NORMAL_READY 0x10000000u
 
 struct Trav {
     Ray ray;
@@ -98,13 +105,101 @@ PT_DEV bool trav_apply(const DScene& sc, Trav& tv, bool hit, float ht, uint32_t 
     return false;
 }
 
+// Starts an estimator evaluation at the point of `ray` at distance t (+ `offset`, in the figure's unit space).
+PT_DEV void frac_start(const DPrim& g, const Ray& ray, float t, uint32_t phase, V3 offset, float* frac) {
+    const float inv_radius = dm::rcp_(g.p[3]);
+    V3 p = (madd(ray.o, ray.d, t) - v3p(g.p)) * inv_radius;  // march_fractal: p * inv_radius; finish_fractal: local
+    if (phase >= FP_N0) p = p + offset;
+    FracIter f;
+    frac_eval_begin(g, p, f);
+#pragma unroll
+    for (int k = 0; k < 9; k++) frac[(FR_S + k) * 64] = f.s[k];
+    ((uint32_t*)frac)[FR_I * 64] = f.i | (phase << 16);
+}
+PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yxy, e.xxx with e = (k, -k)
+    switch (k_index) {
+        case 0: return v3(k, -k, -k);
+        case 1: return v3(-k, -k, k);
+        case 2: return v3(-k, k, -k);
+        default: return v3(k, k, k);
+    }
+}
+// One step of a lane inside a fractal estimator: one iteration and, when the evaluation completes, what the
+// evaluation was for (march_step_fractal's logic around its two sdf calls, or finish_fractal's normal).
+PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park) {
+    PT_SITE(42);
+    uint32_t* frac_u = (uint32_t*)frac;
+    uint32_t* park_u = (uint32_t*)park;
+    const uint32_t word = frac_u[FR_I * 64], phase = word >> 16;
+    const DPrim& g = phase >= FP_N0 ? slot_prim(sc, tv.slot) : sc.prims[tv.pi];
+    FracIter f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) f.s[k] = frac[(FR_S + k) * 64];
+    f.i = word & 0xFFFFu;
+    float value;
+    if (!frac_eval_iter(g, f, value)) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) frac[(FR_S + k) * 64] = f.s[k];
+        frac_u[FR_I * 64] = f.i | (phase << 16);
+        return kind;
+    }
+    if (phase >= FP_N0) {  // finish_fractal / tet_normal: normalize(o0 d0 + o1 d1 + o2 d2 + o3 d3), summed left to right
+        const float k = 0.5773f * PT_EPS * 2.0f;
+        const uint32_t idx = phase - FP_N0;
+        V3 term = tet_offset(idx, k) * value;
+        V3 acc = idx == 0u ? term : v3(park[(PK_N + 0) * 64], park[(PK_N + 1) * 64], park[(PK_N + 2) * 64]) + term;
+        if (idx == 3u) {
+            acc = normalize(acc);
+            park_u[PK_MISC * 64] |= PK_MISC_NORMAL_READY;
+        }
+        park[(PK_N + 0) * 64] = acc.x; park[(PK_N + 1) * 64] = acc.y; park[(PK_N + 2) * 64] = acc.z;
+        if (idx == 3u) return LS_POST;
+        frac_start(g, tv.ray, tv.bound, phase + 1u, tet_offset(idx + 1u, k), frac);
+        return kind;
+    }
+    // march_step_fractal around the evaluation that just completed
+    const float omega = 1.3f;
+    const float radius = g.p[3];
+    MarchState& m = tv.m;
+    int r = MARCH_GO;
+    if (phase == FP_D) {
+        float d = value * radius;
+        if (d < 0.0f && m.prev_d > 0.0f) {
+            m.t -= m.prev_d * (omega - 1.0f);
+            frac_start(g, tv.ray, m.t, FP_D2, v3(0.0f, 0.0f, 0.0f), frac);
+            return kind;
+        }
+        if (dm::abs_(d) < PT_EPS * m.t * 0.5f) r = MARCH_HIT;
+        else {
+            m.t += d * omega;
+            m.prev_d = d;
+            if (m.t > m.max_t) r = MARCH_MISS;
+        }
+    } else {
+        float d2 = value * radius;
+        m.t += d2;
+        m.prev_d = d2;
+    }
+    if (r == MARCH_GO) {
+        m.i += 1u;
+        if (m.i < march_steps) {
+            frac_start(g, tv.ray, m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
+            return kind;
+        }
+        r = MARCH_MISS;
+    }
+    if (trav_apply(sc, tv, r == MARCH_HIT, m.t, 0u)) return LS_POST;
+    tv.pi += 1u;
+    return LS_WALK;
+}
+
 // One WALK step: walk inner nodes until the lane stands at a leaf primitive (same pops, pushes and guards as
 // trace_positive_walk / trace_shadow_walk), then test that primitive, or enter its marcher.  Returns the lane's
 // next state.  `single` (wave-uniform, for deep trees): a step is ONE node visit or ONE primitive test, so no lane
 // waits inside the step for the lane with the longest way down to a leaf (10 M triangles: +10 %; shallow trees
 // lose 1-5 % to the extra scheduling rounds).
 template <bool FRAC>
-PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, bool single) {
+PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, bool single, float* frac) {
     bool walked = false;
     while (tv.pi >= tv.pend) {
         if (single && walked) return LS_WALK;
@@ -156,7 +251,10 @@ PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint3
     } else if (type == FIG_MEBIUS) {
         if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
     } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
-        if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
+        if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) {
+            frac_start(g, tv.ray, tv.m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
+            return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
+        }
     } else if (type != FIG_SKIP) {
         hit = intersect_closed(tv.ray, tv.inv_dir, g, ht, sub);
     }
@@ -172,8 +270,7 @@ PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t m
     int r;
     if (kind == LS_TORUS) { PT_SITE(40); r = march_step_torus(tv.ray, g, tv.m); }
     else if (kind == LS_MEBIUS) { PT_SITE(41); r = march_step_mebius(tv.ray, g, tv.m); }
-    else if (FRAC) { PT_SITE(42); r = march_step_fractal(tv.ray, g, march_steps, tv.m); }
-    else r = MARCH_MISS;
+    else r = MARCH_MISS;  // the fractal kinds step through frac_step
     if (r == MARCH_GO) return kind;
     if (trav_apply(sc, tv, r == MARCH_HIT, tv.m.t, 0u)) return LS_POST;
     tv.pi += 1u;
@@ -307,7 +404,7 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
 // One POST step: everything between the end of a traversal and the start of the lane's next one
 // (path_trace.wgsl:63-179 around the two trace calls; bvh.wgsl:143-232 after the BVH loop).
 template <bool FRAC>
-PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* px_f, uint32_t& job, uint32_t& n_shadow) {
+PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* frac, float* px_f, uint32_t& job, uint32_t& n_shadow) {
     PT_SITE(43);
     const ptx_camera& cam = P.cam;
     uint32_t* park_u = (uint32_t*)park;
@@ -316,15 +413,18 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
     V3 rad = v3(park[(PK_RAD + 0) * 64], park[(PK_RAD + 1) * 64], park[(PK_RAD + 2) * 64]);
     uint32_t rng = park_u[PK_RNG * 64];
     const uint32_t misc = park_u[PK_MISC * 64];
-    uint32_t bounce = misc & 0xFFFFFFu, attempt = (misc >> 24) & 0x7Fu;
+    uint32_t bounce = misc & 0xFFFFFFu, attempt = (misc >> 24) & 0xFu;  // bit 28 is PK_MISC_NORMAL_READY
     const bool lit = (misc >> 31) != 0u;
     bool need_b = false, ended = false, new_ray = false;
     Ray nray;
     nray.o = v3(0.0f, 0.0f, 0.0f);
     nray.d = v3(0.0f, 0.0f, 1.0f);
     if (!tv.shadow) {
+        // A lane whose closest hit is a fractal leaves this step once, to evaluate the normal (four estimator
+        // evaluations) as schedulable iterations, and comes back with the normal parked and this flag set.
+        const bool normal_ready = FRAC && (misc & PK_MISC_NORMAL_READY) != 0u;
         // bvh.wgsl:192-209: planes, tested linearly after the BVH.
-        for (uint32_t i = 0; i < sc.ninf; i++) {
+        for (uint32_t i = 0; i < sc.ninf && !normal_ready; i++) {
             PT_SITE(30);
             const DPrim& g = sc.inf[i];
             float ht;
@@ -336,7 +436,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             }
         }
         // bvh.wgsl:143-188: a hit inside a subtraction shape restarts the traversal behind that shape, up to 8 times.
-        if (sc.nneg > 0u && tv.slot != PT_SLOT_NONE && attempt < 8u) {
+        if (sc.nneg > 0u && tv.slot != PT_SLOT_NONE && attempt < 8u && !normal_ready) {
             V3 hp = madd(tv.ray.o, tv.ray.d, tv.bound);
             if (inside_any_negative(sc, hp)) {
                 float min_exit = PT_MAX_T;
@@ -349,6 +449,14 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
                     trav_begin(sc, tv, false, PT_MAX_T);
                     return LS_WALK;
                 }
+            }
+        }
+        if (FRAC && !normal_ready && tv.slot != PT_SLOT_NONE) {
+            const DPrim& gw = slot_prim(sc, tv.slot);
+            if (gw.type == FIG_MANDELBULB || gw.type == FIG_JULIA) {
+                park_u[PK_MISC * 64] = bounce | (attempt << 24);  // the planes may have moved bound / slot: those live in tv
+                frac_start(gw, tv.ray, tv.bound, FP_N0, tet_offset(0u, 0.5773f * PT_EPS * 2.0f), frac);
+                return gw.type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
             }
         }
         PT_SITE(32);
@@ -365,7 +473,14 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             const ptx_material mt = sh.mat;
             bool need_uv = mt.texture_id >= 0;
             HitFull h;
-            resolve_hit<FRAC>(tv.ray, tv.inv_dir, g, tv.bound, tv.sub, need_uv, &sh, &h);
+            if (normal_ready) {  // finish_fractal with the normal evaluated by frac_step
+                h.pos = madd(tv.ray.o, tv.ray.d, tv.bound);
+                h.normal = v3(park[(PK_N + 0) * 64], park[(PK_N + 1) * 64], park[(PK_N + 2) * 64]);
+                h.uv.x = 0.0f;
+                h.uv.y = 0.0f;
+            } else {
+                resolve_hit<FRAC>(tv.ray, tv.inv_dir, g, tv.bound, tv.sub, need_uv, &sh, &h);
+            }
             V3 base_color = v3p(mt.base_color);
             if (need_uv) {
                 V2 tuv;

@@ -14,6 +14,8 @@ CASES = [("cornell_box", 1920, 1080, (32, 128)), ("teapot", 3840, 2160, (8,)), (
 print("library:", _lib.LIB_PATH)
 if len(sys.argv) > 1:
     CASES = [c for c in CASES if c[0] in sys.argv[1:]]
+if os.environ.get("PROBE_N"):  # samples per launch, e.g. PROBE_N=2,8
+    CASES = [(c[0], c[1], c[2], tuple(int(x) for x in os.environ["PROBE_N"].split(","))) for c in CASES]
 pt = PathTracer(0)
 for name, w, h, ns in CASES:
     sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
