@@ -44,12 +44,21 @@ static __device__ __noinline__ void pt_site_hist(int base, uint32_t n) {  // his
         atomicAdd(&pt_sites[2 * b + 1], (unsigned long long)n);
     }
 }
+static __device__ __noinline__ void pt_site_add(int i, uint32_t n) {  // mean of a wave-uniform count
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+        atomicAdd(&pt_sites[2 * i], 1ull);
+        atomicAdd(&pt_sites[2 * i + 1], (unsigned long long)n);
+    }
+}
 #define PT_SITE(i) pt_site(i)
 #define PT_SITE_HIST(b, n) pt_site_hist(b, n)
+#define PT_SITE_ADD(i, n) pt_site_add(i, n)
 #define PT_SITE_TYPED(b, t) pt_site_typed(b, t)
 #else
 #define PT_SITE(i)
 #define PT_SITE_HIST(b, n)
+#define PT_SITE_ADD(i, n)
 #define PT_SITE_TYPED(b, t)
 #endif
 

@@ -242,20 +242,21 @@ PT_DEV void sched_body(const TraceParams& P) {
     tv.m.t = 0.0f; tv.m.prev_d = 0.0f; tv.m.max_t = 0.0f; tv.m.i = 0u;
     uint32_t S = LS_IDLE;
     uint32_t job = blockIdx.x * PTX_BLOCK + threadIdx.x;  // the first job of every lane; the counter starts behind them
+    const bool split = FRAC && P.split_n > 0u;  // jobs are single samples (TraceParams::split_n)
     if (P.n > 0u) {
         PixelJob J;
-        if (claim_pixel(P, job, true, px_f, J)) {
+        if (claim_pixel(P, job, true, px_f, J, split)) {
             Ray r0;
             r0.o = v3(0.0f, 0.0f, 0.0f);
             r0.d = v3(0.0f, 0.0f, 1.0f);
-            S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u);
+            S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u, split);
         }
     }
     // The scheduler.  A state is served when at least 1/share of the wave's live lanes wait in it, WALK before
     // POST before the fullest marcher; a marcher then keeps stepping while three quarters of its lanes are
     // still marching.  When no state reaches its share the fullest one is served, so every round makes
     // progress.  The shares are set per scene class by the host (measured): meshes walk whenever any lane can
-    // (64, 2, 4), meshes with ray-marched figures 8, 2, 4, fractal scenes 8, 4, 4, small scenes with a Moebius strip 4, 2, 4.
+    // (64, 2, 4), meshes with ray-marched figures 8, 2, 4, fractal scenes 64, 8, 4, small scenes with a Moebius strip 4, 2, 4.
     for (;;) {
         uint32_t pop[LS_COUNT];
         uint32_t live = 0u, fullest = LS_IDLE, fullest_n = 0u, march = LS_IDLE, march_n = 0u;
@@ -278,12 +279,19 @@ PT_DEV void sched_body(const TraceParams& P) {
                 if (w == 0u || w * P.share_walk < live) break;
             }
         } else if (pick == LS_POST) {
-            if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow);
+            if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
         } else {
             const uint32_t n0 = pop[pick];
             for (;;) {
                 PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(S == pick)));
                 PT_SITE_HIST(60, live);
+                if (live >= 57u) {  // what a full wave's lanes are doing while a marcher steps
+                    PT_SITE_ADD(70, (uint32_t)__popcll(__ballot(S == LS_WALK)));
+                    PT_SITE_ADD(71, (uint32_t)__popcll(__ballot(S == LS_POST)));
+                    PT_SITE_ADD(72, (uint32_t)__popcll(__ballot(S == LS_MANDEL)));
+                    PT_SITE_ADD(73, (uint32_t)__popcll(__ballot(S == LS_JULIA)));
+                    PT_SITE_ADD(74, (uint32_t)__popcll(__ballot(S == LS_IDLE)));
+                }
                 if (S == pick) S = (FRAC && pick >= (uint32_t)LS_MANDEL) ? frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park)
                                                                         : march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps);
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
@@ -293,10 +301,40 @@ PT_DEV void sched_body(const TraceParams& P) {
     }
     const uint32_t n_bounce = px_u[7 * 64];
     uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
-    if (lane == 0u && P.stats) {  // paths were added pixel by pixel
+    const uint32_t sp = split ? wave_sum(px_u[6 * 64]) : 0u;
+    if (lane == 0u && P.stats) {  // without split jobs the paths were added pixel by pixel
+        if (split) atomicAdd(&P.stats[0], (unsigned long long)sp);
         atomicAdd(&P.stats[1], (unsigned long long)sb);
         atomicAdd(&P.stats[2], (unsigned long long)ss);
     }
+}
+
+// Folds the staged samples of each pixel job into the pixel's running mean (and second moment), in sample
+// order, with the arithmetic of next_path; one lane per pixel job of the launch.
+extern "C" __global__ void __launch_bounds__(256) ptx_fold_kernel(const TraceParams P) {
+    PixelJob J;
+    if (!job_pixel(P, blockIdx.x * 256u + threadIdx.x, J)) return;
+    float4 a = P.accum[J.pix];
+    V3 mean = v3(a.x, a.y, a.z);
+    V3 m2 = v3(0.0f, 0.0f, 0.0f);
+    if (P.m2) m2 = v3(P.m2[J.pix * 3], P.m2[J.pix * 3 + 1], P.m2[J.pix * 3 + 2]);
+    for (uint32_t k = 0; k < P.n; k++) {
+        float4 s = P.staging[(size_t)k * P.frame_pixels + J.pix];
+        V3 r = v3(s.x, s.y, s.z);
+        float nn = dm::fmax_((float)(P.first_sample + k), 1.0f);
+        V3 delta = r - mean;
+        V3 nm = mean + vdivs(delta, nn);
+        if (P.m2) {
+            V3 d2 = r - nm;
+            m2.x = dm::fma_(delta.x, d2.x, m2.x);
+            m2.y = dm::fma_(delta.y, d2.y, m2.y);
+            m2.z = dm::fma_(delta.z, d2.z, m2.z);
+        }
+        mean = nm;
+    }
+    P.accum[J.pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+    if (P.m2) { P.m2[J.pix * 3] = m2.x; P.m2[J.pix * 3 + 1] = m2.y; P.m2[J.pix * 3 + 2] = m2.z; }
+    P.out_rgba8[J.pix] = tonemap_rgba8(P.cam, mean);
 }
 
 // Four variants: scene records in global memory or staged in LDS; with or without the fractal marchers.
@@ -481,6 +519,9 @@ struct ptx_ctx {
     uint32_t shares[3] = {4u, 2u, 4u};  // their scheduling shares (walk, post, march)
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
+    bool split = true;            // scheduled fractal kernels: sample-granular jobs + fold (PTX355_SPLIT=0 turns it off)
+    float4* staging = nullptr;    // their staged samples, [sample][frame pixel]
+    size_t staging_n = 0;
     const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
     size_t occ_lds = 0;
     int occ_per_cu = 0;
@@ -676,6 +717,7 @@ void ptx_destroy(ptx_ctx* c) {
     free_frame(c);
     if (c->stats) (void)hipFree(c->stats);
     if (c->wave_tiles) (void)hipFree(c->wave_tiles);
+    if (c->staging) (void)hipFree(c->staging);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -865,13 +907,14 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     c->have_scene = true;
     c->sched = pick_sched(sc, dprims);
     {
-        const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {8u, 4u, 4u}, small[3] = {4u, 2u, 4u};
+        const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {4u, 2u, 4u};
         bool marchers = false;
         for (const DPrim& g : dprims) marchers = marchers || g.type == FIG_TORUS || g.type == FIG_MEBIUS || g.type == FIG_MANDELBULB || g.type == FIG_JULIA;
         const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
         memcpy(c->shares, pick, sizeof(c->shares));
         c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
         if (const char* e = getenv("PTX355_CLAIM_TILE")) c->claim_tile = atoi(e) > 1 ? 64u : 1u;
+        if (const char* e = getenv("PTX355_SPLIT")) c->split = e[0] != '0';
         if (const char* e = getenv("PTX355_SHARES")) {  // measurement runs: "walk,post,march"
             unsigned w = 0, p = 0, m = 0;
             if (sscanf(e, "%u,%u,%u", &w, &p, &m) == 3 && w && p && m) { c->shares[0] = w; c->shares[1] = p; c->shares[2] = m; }
@@ -988,15 +1031,48 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         P.claim_tile = c->claim_tile;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= 20u ? 1u : 0u;  // trees deeper than ~20 levels (millions of primitives)
-        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
+    }
+    // Fractal scenes: a pixel on a fractal's silhouette costs hundreds of times a background pixel, and with one
+    // lane folding all n samples of its pixel the launch ends on a few lanes finishing theirs.  There the jobs
+    // are single samples, staged and folded in order by ptx_fold_kernel, in chunks that bound the staging buffer
+    // (1 GiB) and the job count.  Radiance capture keeps whole-pixel jobs (its sample index is launch-relative).
+    const bool split = c->sched && frac && c->split && n > 1u && !c->dbg;
+    uint32_t chunk = n;
+    if (split) {
+        const size_t frame_pixels = (size_t)c->w * c->h;
+        size_t by_mem = ((size_t)1 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)P.n_blocks * 256u);
+        size_t m = by_mem < by_jobs ? by_mem : by_jobs;
+        if (const char* e = getenv("PTX355_SPLIT_CHUNK")) { size_t v = (size_t)atoi(e); if (v >= 1 && v < m) m = v; }  // tests
+        if (m < 1) m = 1;
+        if (m < chunk) chunk = (uint32_t)m;
+        if (chunk * frame_pixels > c->staging_n) {
+            if (c->staging) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->staging); c->staging = nullptr; c->staging_n = 0; }
+            HIP_TRY(c, hipMalloc((void**)&c->staging, chunk * frame_pixels * sizeof(float4)));
+            c->staging_n = chunk * frame_pixels;
+        }
+        P.staging = c->staging;
+        P.frame_pixels = (uint32_t)frame_pixels;
     }
     if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
     hipEvent_t e0, e1;
     int rc;
     if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
-    HIP_TRY(c, hipGetLastError());
+    for (uint32_t done = 0; done < n; done += chunk) {
+        const uint32_t m = n - done < chunk ? n - done : chunk;
+        P.first_frame = first_frame + done; P.first_sample = first_sample + done; P.n = m;
+        if (split && m > 1u) { P.split_n = m; P.total_jobs = P.n_blocks * 256u * m; }
+        else { P.split_n = 0u; P.total_jobs = P.n_blocks * 256u; }
+        if (claim) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
+        HIP_TRY(c, hipGetLastError());
+        if (P.split_n > 0u) {
+            TraceParams F = P;
+            F.split_n = 0u;
+            hipLaunchKernelGGL(ptx_fold_kernel, dim3(P.n_blocks), dim3(256), 0, c->stream, F);
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->pending.push_back({e0, e1});
     return PTX_OK;

@@ -39,6 +39,11 @@ struct TraceParams {
     uint32_t total_jobs;    // n_blocks * 256
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
     uint32_t walk_single;   // scheduled kernels: one node visit per WALK step (deep trees)
+    // Sample-granular jobs (scheduled fractal kernels, split_n > 0): job j is sample j % split_n of pixel job
+    // j / split_n; a finished sample's radiance goes to staging[sample * frame_pixels + pixel] and the fold
+    // kernel folds the samples of each pixel into its running mean in sample order afterwards.
+    uint32_t split_n, frame_pixels;
+    float4* staging;
 };
 
 enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS = 4, LS_MANDEL = 5, LS_JULIA = 6, LS_COUNT = 7 };
@@ -283,8 +288,14 @@ PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t m
 // pixel).  Job j is pixel (j & 255) of this launch's 16x16 block (j >> 8), 8x8 quadrant by quadrant; all the
 // samples of a pixel are still folded in order by the one lane that owns it, so results do not depend on which
 // lane that is.
-struct PixelJob { uint32_t tx, ty, px, py; size_t pix; };
-PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J) {
+struct PixelJob { uint32_t tx, ty, px, py, k; size_t pix; };
+PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J, bool split = false) {
+    J.k = 0u;
+    if (split) {
+        const uint32_t pj = job / P.split_n;
+        J.k = job - pj * P.split_n;
+        job = pj;
+    }
     const uint32_t blk = (job >> 8) * P.part_world + P.part_rank, p = job & 255u;
     const uint32_t bx = blk % P.blocks_x, by = blk / P.blocks_x, q = p >> 6, l = p & 63u;
     J.tx = bx * 16u + (q & 1u) * 8u + (l & 7u);
@@ -302,7 +313,7 @@ PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J) {
 // marcher (+4 % / +18 %).  With claim_tile == 1 every lane claims single pixels from the counter: heavy pixels
 // spread over all waves, which serves the fractal scenes (a whole quadrant of silhouette pixels in one wave
 // costs 23 %) and, slightly, the Cornell box.
-PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate, float* px_f, PixelJob& J) {
+PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate, float* px_f, PixelJob& J, bool split = false) {
     uint32_t* px_u = (uint32_t*)px_f;
     uint2* wt = P.wave_tiles + (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     for (;;) {
@@ -326,7 +337,11 @@ PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate
         }
         have_candidate = false;
         if (job >= P.total_jobs) return false;
-        if (job_pixel(P, job, J)) break;
+        if (job_pixel(P, job, J, split)) break;
+    }
+    if (split) {  // the pixel's accumulator stays in memory until the fold; its last sample owns the primary id
+        if (J.k + 1u == P.split_n) P.primary_ids[J.pix] = 0xFFFFFFFFu;
+        return true;
     }
     float4 a = P.accum[J.pix];
     px_f[0 * 64] = a.x; px_f[1 * 64] = a.y; px_f[2 * 64] = a.z;
@@ -341,14 +356,22 @@ PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate
 // camera ray of the next sample (random.wgsl:12-14, camera.wgsl:6-19); then starts the closest-hit traversal of
 // `nray`.  `fresh`: the lane has just claimed `job` and has no sample to fold yet.  Returns the lane's next state.
 PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* px_f, uint32_t& job, bool fresh, bool ended,
-                          Ray nray, V3 thr, V3 rad, uint32_t rng, uint32_t bounce) {
+                          Ray nray, V3 thr, V3 rad, uint32_t rng, uint32_t bounce, bool split = false) {
     const ptx_camera& cam = P.cam;
     uint32_t* park_u = (uint32_t*)park;
     uint32_t* px_u = (uint32_t*)px_f;
     while (ended || fresh) {
         PixelJob J;
         uint32_t k_next = 0u;
-        if (!fresh) {
+        if (!fresh && split) {
+            PT_SITE(36);
+            job_pixel(P, job, J, true);
+            V3 r = v3(dm::fmax_(rad.x, 0.0f), dm::fmax_(rad.y, 0.0f), dm::fmax_(rad.z, 0.0f));
+            P.staging[(size_t)J.k * P.frame_pixels + J.pix] = make_float4(r.x, r.y, r.z, 0.0f);
+            px_u[6 * 64] += 1u;  // here: paths this lane has finished
+            if (!claim_pixel(P, job, false, px_f, J, true)) return LS_IDLE;
+            k_next = J.k;
+        } else if (!fresh) {
             PT_SITE(36);
             job_pixel(P, job, J);
             const uint32_t k = px_u[6 * 64];
@@ -381,7 +404,8 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
                 k_next = 0u;
             }
         } else {
-            job_pixel(P, job, J);
+            job_pixel(P, job, J, split);
+            k_next = J.k;
         }
         fresh = false;
         rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + k_next) * 16777259u);
@@ -404,7 +428,7 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
 // One POST step: everything between the end of a traversal and the start of the lane's next one
 // (path_trace.wgsl:63-179 around the two trace calls; bvh.wgsl:143-232 after the BVH loop).
 template <bool FRAC>
-PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* frac, float* px_f, uint32_t& job, uint32_t& n_shadow) {
+PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* frac, float* px_f, uint32_t& job, uint32_t& n_shadow, bool split) {
     PT_SITE(43);
     const ptx_camera& cam = P.cam;
     uint32_t* park_u = (uint32_t*)park;
@@ -554,7 +578,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
                                 V3 contrib = vdivs(thr * v3p(L.le) * brdf * n_dot_l * w, pa);
                                 park[(PK_CONTRIB + 0) * 64] = contrib.x; park[(PK_CONTRIB + 1) * 64] = contrib.y; park[(PK_CONTRIB + 2) * 64] = contrib.z;
                                 n_shadow += 1u;
-                                if (first) { PixelJob J; job_pixel(P, job, J); P.primary_ids[J.pix] = fig; }
+                                if (first) { PixelJob J; job_pixel(P, job, J, split); if (!split || J.k + 1u == P.split_n) P.primary_ids[J.pix] = fig; }
                                 park[(PK_THR + 0) * 64] = thr.x; park[(PK_THR + 1) * 64] = thr.y; park[(PK_THR + 2) * 64] = thr.z;
                                 park[(PK_RAD + 0) * 64] = rad.x; park[(PK_RAD + 1) * 64] = rad.y; park[(PK_RAD + 2) * 64] = rad.z;
                                 park_u[PK_RNG * 64] = rng;
@@ -570,7 +594,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
                 }
             }
         }
-        if (first) { PixelJob J; job_pixel(P, job, J); P.primary_ids[J.pix] = fig; }
+        if (first) { PixelJob J; job_pixel(P, job, J, split); if (!split || J.k + 1u == P.split_n) P.primary_ids[J.pix] = fig; }
     } else {
         // bvh.wgsl:212-232: the plane list of the occlusion query, unless the BVH already gave an occluder.
         bool occluded = tv.slot != PT_SLOT_NONE;
@@ -618,5 +642,5 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
         }
     }
     if (new_ray && bounce >= cam.max_bounces) ended = true;  // path_trace.wgsl:63
-    return next_path(sc, P, tv, park, px_f, job, false, ended, nray, thr, rad, rng, bounce);
+    return next_path(sc, P, tv, park, px_f, job, false, ended, nray, thr, rad, rng, bounce, split);
 }

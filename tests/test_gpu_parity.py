@@ -385,28 +385,33 @@ def test_error_reporting(pt):
     fresh.close()
 
 
-@pytest.mark.parametrize("name,w,h,n", [("cornell_box", 160, 90, 5), ("teapot", 200, 112, 3), ("fractals", 64, 36, 2), ("all", 128, 72, 3)])
+@pytest.mark.parametrize("name,w,h,n", [("cornell_box", 160, 90, 5), ("teapot", 200, 112, 3), ("fractals", 64, 36, 3), ("all", 128, 72, 3)])
 def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w, h, n, monkeypatch):
     """The lockstep and the wave-scheduled kernels, with single-pixel and 64-pixel claims, are interchangeable:
     same accumulation, M2, ids, rgba8 and counters on every scene (the host picks per scene; here each is forced)."""
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
     cam = sc.camera(w, h)
     results = {}
-    for sched, tile in (("0", "1"), ("1", "1"), ("1", "64"), ("0", "64")):
+    # split: the scheduled fractal kernels' sample-granular jobs + fold ("2": in chunks of two samples)
+    for sched, tile, split in (("0", "1", "0"), ("1", "1", "0"), ("1", "1", "1"), ("1", "1", "2"), ("1", "64", "0"), ("0", "64", "0")):
         monkeypatch.setenv("PTX355_SCHED", sched)
         monkeypatch.setenv("PTX355_CLAIM_TILE", tile)
+        monkeypatch.setenv("PTX355_SPLIT", "0" if split == "0" else "1")
+        monkeypatch.setenv("PTX355_SPLIT_CHUNK", "2" if split == "2" else "1000")
         sc.upload_to(pt)  # the family is chosen at upload
         assert ("sched" in pt.kernel_name()) == (sched == "1")
         pt.enable_moments(True)
         pt.resize(w, h)
         pt.trace_n(cam, 0, 1, n)
         st = pt.stats()
-        results[(sched, tile)] = (pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
+        results[(sched, tile, split)] = (pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
                                   (st["paths"], st["bounces"], st["shadow_rays"]))
         pt.enable_moments(False)
     monkeypatch.delenv("PTX355_SCHED")
     monkeypatch.delenv("PTX355_CLAIM_TILE")
-    ref = results[("0", "1")]
+    monkeypatch.delenv("PTX355_SPLIT")
+    monkeypatch.delenv("PTX355_SPLIT_CHUNK")
+    ref = results[("0", "1", "0")]
     for key, r in results.items():
         assert same_bits(r[0], ref[0]) == 0 and same_bits(r[1], ref[1]) == 0, key
         assert (r[2] == ref[2]).all() and (r[3] == ref[3]).all() and r[4] == ref[4], key

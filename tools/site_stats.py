@@ -22,6 +22,8 @@ TYPES = ["sphere", "plane", "cube", "cylinder", "cone", "torus", "disc", "triang
 for b in range(8):
     NAMES[50 + b] = f"march round, {8 * b + 1}-{8 * b + 8} lanes"
     NAMES[60 + b] = f"  ... of {8 * b + 1}-{8 * b + 8} live"
+for i, t in enumerate(("WALK", "POST", "MANDEL", "JULIA", "IDLE")):
+    NAMES[70 + i] = f"full wave marching: in {t}"
 for i, t in enumerate(TYPES):
     NAMES[10 + i] = "test " + t
 
