@@ -63,6 +63,16 @@ int pth_scene_provide_texture(pth_scene* s, uint32_t i, const uint8_t* rgba8, ui
  * src/accel/aabb.rs; src/io/texture_atlas.rs).  Must be called before the getters below. */
 int pth_scene_build(pth_scene* s);
 
+/* A BVH builder over n primitive boxes (n x {min xyz, max xyz}): fills max(1, 2n) nodes / n primitive positions
+ * and returns 0.  pth_bvh_build is Bvh::build (src/accel/bvh.rs:37-213) on the host; the device library's
+ * ptx_bvh_build has the same signature with its context as `user` and gives the same arrays. */
+typedef int (*pth_bvh_fn)(void* user, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                          uint32_t* prim_indices_out);
+int pth_bvh_build(void* user, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                  uint32_t* prim_indices_out);
+/* pth_scene_build with the tree built by `bvh` (user passed through). */
+int pth_scene_build_with(pth_scene* s, pth_bvh_fn bvh, void* user);
+
 const ptx_shape* pth_scene_figures(const pth_scene* s, uint32_t* n);
 const ptx_material* pth_scene_materials(const pth_scene* s, uint32_t* n);
 const ptx_bvh_node* pth_scene_bvh_nodes(const pth_scene* s, uint32_t* n);

@@ -144,6 +144,16 @@ int ptx_sync(ptx_ctx* ctx);
 int ptx_read_accum(ptx_ctx* ctx, float* rgba_f32);
 int ptx_read_output(ptx_ctx* ctx, uint8_t* rgba8);
 
+/* Bvh::build (src/accel/bvh.rs:37-213) on the GPU: the binned-SAH tree over n primitive boxes (aabbs: n x {min xyz,
+ * max xyz}, as shape_aabb gives them, src/accel/aabb.rs:105-174), with the flat node array and the primitive order
+ * of the reference's sequential builder reproduced exactly.  nodes_out has room for max(1, 2n) nodes,
+ * prim_indices_out for n indices (positions in aabbs; the caller remaps them to figure indices as
+ * src/app/state.rs:543-567 does).  Synchronous.  The scene is not touched: pass the result to ptx_upload_scene.
+ * A bound that is a zero is returned as +0.0 whatever the sign of the zeros it was taken over; a box holding a NaN
+ * is refused (PTX_ERR_BAD_ARG).  Device memory while it runs: about 270 bytes per primitive. */
+int ptx_bvh_build(ptx_ctx* ctx, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                  uint32_t* prim_indices_out);
+
 /* The reverse of ptx_read_accum / ptx_read_moments (no reference counterpart; its accumulation buffer only ever
  * lives on the device): loads w*h*4 floats into the accumulation buffer and, when m2 is not NULL and moments are
  * enabled, w*h*3 floats into the M2 buffer, to resume a progressive render (continue with first_sample =

@@ -32,6 +32,7 @@ SYMBOLS = [
     ("ptx_write_accum", C.c_int, [_P, _P, _P]),
     ("ptx_read_output", C.c_int, [_P, _P]),
     ("ptx_read_primary_ids", C.c_int, [_P, _P]),
+    ("ptx_bvh_build", C.c_int, [_P, _P, _U, _P, C.POINTER(_U), _P]),
     ("ptx_debug_capture", C.c_int, [_P, _U]),
     ("ptx_read_debug_radiance", C.c_int, [_P, _P, _U]),
     ("ptx_enable_moments", C.c_int, [_P, C.c_int]),

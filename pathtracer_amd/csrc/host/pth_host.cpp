@@ -786,8 +786,37 @@ int pth_scene_provide_texture(pth_scene* s, uint32_t i, const uint8_t* rgba8, ui
     return 0;
 }
 
-int pth_scene_build(pth_scene* s) {
-    if (!s) return -1;
+// Bvh::build over plain arrays (bvh.rs:37-57), the host form of pth_bvh_fn.
+int pth_bvh_build(void* /*user*/, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* prim_indices_out) {
+    if (!nodes_out || !n_nodes_out || (n > 0 && (!aabbs || !prim_indices_out))) return -1;
+    if (n == 0) {  // bvh.rs:38-43
+        memset(nodes_out, 0, sizeof(ptx_bvh_node));
+        *n_nodes_out = 1;
+        return 0;
+    }
+    std::vector<Aabb> boxes(n);
+    for (uint32_t k = 0; k < n; k++) boxes[k] = {mk(aabbs + (size_t)k * 6), mk(aabbs + (size_t)k * 6 + 3)};
+    BvhBuilder b(boxes);
+    b.build();
+    // bvh.rs:188-213: the build order is already the pre-order of `flatten`, so node i of the build list is
+    // node i of the flat array and the right child index is the build index.
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        const BuildNode& bn = b.nodes[i];
+        ptx_bvh_node& o = nodes_out[i];
+        o.aabb_min[0] = bn.bounds.mn.x; o.aabb_min[1] = bn.bounds.mn.y; o.aabb_min[2] = bn.bounds.mn.z;
+        o.aabb_max[0] = bn.bounds.mx.x; o.aabb_max[1] = bn.bounds.mx.y; o.aabb_max[2] = bn.bounds.mx.z;
+        if (bn.count > 0) { o.left_or_prim = (uint32_t)bn.first; o.prim_count = (uint32_t)bn.count; }
+        else { o.left_or_prim = (uint32_t)bn.right; o.prim_count = 0; }
+    }
+    *n_nodes_out = (uint32_t)b.nodes.size();
+    memcpy(prim_indices_out, b.indices.data(), (size_t)n * 4);
+    return 0;
+}
+
+int pth_scene_build(pth_scene* s) { return pth_scene_build_with(s, pth_bvh_build, nullptr); }
+
+int pth_scene_build_with(pth_scene* s, pth_bvh_fn bvh, void* user) {
+    if (!s || !bvh) return -1;
     collect_textures(s);
     // texture_atlas.rs:26-79 + state.rs:328-348
     s->tex_pixels.assign(1, 0xFF808080u);
@@ -849,29 +878,21 @@ int pth_scene_build(pth_scene* s) {
         else if (s->shapes[i].type == 8u) {}
         else finite.push_back((uint32_t)i);
     }
-    std::vector<Aabb> boxes(finite.size());
-    for (size_t k = 0; k < finite.size(); k++) boxes[k] = shape_aabb(s->shapes[finite[k]]);
-    s->nodes.clear();
-    s->prims.clear();
-    if (boxes.empty()) {
-        s->nodes.push_back(ptx_bvh_node{});  // bvh.rs:38-43
-    } else {
-        BvhBuilder b(boxes);
-        b.build();
-        // bvh.rs:188-213: the build order above is already the pre-order of `flatten`, so node i of the
-        // build list is node i of the flat array and the right child index is the build index.
-        s->nodes.resize(b.nodes.size());
-        for (size_t i = 0; i < b.nodes.size(); i++) {
-            const BuildNode& bn = b.nodes[i];
-            ptx_bvh_node& o = s->nodes[i];
-            o.aabb_min[0] = bn.bounds.mn.x; o.aabb_min[1] = bn.bounds.mn.y; o.aabb_min[2] = bn.bounds.mn.z;
-            o.aabb_max[0] = bn.bounds.mx.x; o.aabb_max[1] = bn.bounds.mx.y; o.aabb_max[2] = bn.bounds.mx.z;
-            if (bn.count > 0) { o.left_or_prim = (uint32_t)bn.first; o.prim_count = (uint32_t)bn.count; }
-            else { o.left_or_prim = (uint32_t)bn.right; o.prim_count = 0; }
-        }
-        s->prims.resize(b.indices.size());
-        for (size_t k = 0; k < b.indices.size(); k++) s->prims[k] = finite[b.indices[k]];
+    std::vector<float> boxes(finite.size() * 6);
+    for (size_t k = 0; k < finite.size(); k++) {
+        Aabb b = shape_aabb(s->shapes[finite[k]]);
+        float* o = boxes.data() + k * 6;
+        o[0] = b.mn.x; o[1] = b.mn.y; o[2] = b.mn.z; o[3] = b.mx.x; o[4] = b.mx.y; o[5] = b.mx.z;
     }
+    s->nodes.assign(std::max<size_t>(1, 2 * finite.size()), ptx_bvh_node{});
+    s->prims.assign(finite.size(), 0u);
+    uint32_t n_nodes = 0;
+    if (int rc = bvh(user, boxes.data(), (uint32_t)finite.size(), s->nodes.data(), &n_nodes, s->prims.data())) {
+        s->err = "the BVH builder failed with code " + std::to_string(rc);
+        return -2;
+    }
+    s->nodes.resize(n_nodes);
+    for (size_t k = 0; k < s->prims.size(); k++) s->prims[k] = finite[s->prims[k]];  // state.rs:559-565: leaf indices -> figure indices
     s->built = true;
     return 0;
 }

@@ -19,6 +19,7 @@
 #include <vector>
 #include "sched_dev.h"
 #include "post_dev.h"
+#include "bvh_build.h"
 
 #define PTX_BLOCK 256
 #define PTX_WAVES_PER_BLOCK 4
@@ -1184,6 +1185,126 @@ extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
     return 0;
 }
 #endif
+
+// ---- GPU BVH build (bvh_build.h) ---------------------------------------------------------------------------------------
+namespace {
+struct DevBufs {  // device allocations of one build, released on every exit path
+    std::vector<void*> ptrs;
+    ~DevBufs() { for (void* p : ptrs) (void)hipFree(p); }
+    hipError_t alloc(void** out, size_t bytes) {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+};
+int scan_u32(ptx_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* sums) {
+    const uint32_t nblocks = (n + bvhb::SCAN_TILE - 1u) / bvhb::SCAN_TILE;
+    hipLaunchKernelGGL(bvhb::scan_sums_kernel, dim3(nblocks), dim3(256), 0, c->stream, in, n, sums);
+    hipLaunchKernelGGL(bvhb::scan_top_kernel, dim3(1), dim3(256), 0, c->stream, sums, nblocks, out + n);
+    hipLaunchKernelGGL(bvhb::scan_final_kernel, dim3(nblocks), dim3(256), 0, c->stream, in, n, (const uint32_t*)sums, out);
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+}  // namespace
+
+int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* prim_indices_out) {
+    if (!c || !nodes_out || !n_nodes_out || (n > 0u && (!aabbs || !prim_indices_out))) return PTX_ERR_BAD_ARG;
+    if (n == 0u) {  // bvh.rs:38-43
+        memset(nodes_out, 0, sizeof(ptx_bvh_node));
+        *n_nodes_out = 1u;
+        return PTX_OK;
+    }
+    if (n > 0x3FFFFFFFu) return fail(c, PTX_ERR_BAD_ARG, "ptx_bvh_build: more than 2^30 primitives");
+    HIP_TRY(c, hipSetDevice(c->device));
+    using namespace bvhb;
+    DevBufs mem;
+    float *d_aabb, *d_cent;
+    uint32_t *d_idx[2], *d_seg, *d_pass, *d_P, *d_X, *d_Y, *d_flag, *d_rank, *d_sums, *d_bins, *d_counter;
+    Rec* d_recs;
+    FlatNode* d_nodes;
+    const size_t big_cap = (size_t)n / SMALL_MAX + 2u;
+    HIP_TRY(c, mem.alloc((void**)&d_aabb, (size_t)n * 24));
+    HIP_TRY(c, mem.alloc((void**)&d_cent, (size_t)n * 12));
+    HIP_TRY(c, mem.alloc((void**)&d_idx[0], (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_idx[1], (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_seg, (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_pass, (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_P, ((size_t)n + 1) * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_X, (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_Y, (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_flag, (size_t)n * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_rank, ((size_t)n + 1) * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_sums, ((size_t)n / SCAN_TILE + 2) * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_bins, big_cap * BIN_WORDS * 4));
+    HIP_TRY(c, mem.alloc((void**)&d_counter, 8));  // [0] ranges above SMALL_MAX of the next level, [1] NaN seen
+    HIP_TRY(c, mem.alloc((void**)&d_recs, (size_t)n * 2 * sizeof(Rec)));
+    HIP_TRY(c, mem.alloc((void**)&d_nodes, (size_t)n * 2 * sizeof(FlatNode)));
+    hipStream_t st = c->stream;
+    const uint32_t pos_blocks = (n + 255u) / 256u;
+    HIP_TRY(c, hipMemcpyAsync(d_aabb, aabbs, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(d_counter, 0, 8, st));
+    hipLaunchKernelGGL(prep_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const float*)d_aabb, d_cent, d_idx[0], d_seg, d_counter + 1);
+    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, st, d_recs, n, d_counter);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t has_nan = 0u;
+    HIP_TRY(c, hipMemcpyAsync(&has_nan, d_counter + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (has_nan) return fail(c, PTX_ERR_BAD_ARG, "ptx_bvh_build: a box holds a NaN");
+    std::vector<std::pair<uint32_t, uint32_t>> levels;  // {first record, records} per level
+    uint32_t base = 0u, nseg = 1u, nbig = n > SMALL_MAX ? 1u : 0u, cur = 0u;
+    for (;;) {
+        if (levels.size() >= 8192u) return fail(c, PTX_ERR_STATE, "ptx_bvh_build: tree deeper than 8192 levels");
+        levels.push_back({base, nseg});
+        const uint32_t seg_blocks = (nseg + 255u) / 256u;
+        // bounds of every range of the level; bins and the split of its inner ranges
+        if (nbig > 0u) {
+            hipLaunchKernelGGL(bounds_big_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, d_recs, (const uint32_t*)d_idx[cur], (const float*)d_aabb);
+            hipLaunchKernelGGL(bins_clear_kernel, dim3(nbig), dim3(256), 0, st, d_bins, nbig);
+            hipLaunchKernelGGL(bins_big_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, (const Rec*)d_recs, (const uint32_t*)d_idx[cur],
+                               (const float*)d_aabb, (const float*)d_cent, d_bins);
+            hipLaunchKernelGGL(split_big_kernel, dim3(seg_blocks), dim3(256), 0, st, d_recs, base, nseg, (const uint32_t*)d_bins);
+        }
+        hipLaunchKernelGGL(seg_small_kernel, dim3((nseg + 3u) / 4u), dim3(256), 0, st, d_recs, base, nseg, (const uint32_t*)d_idx[cur], (const float*)d_aabb, (const float*)d_cent);
+        hipLaunchKernelGGL(inner_flag_kernel, dim3(seg_blocks), dim3(256), 0, st, (const Rec*)d_recs, base, nseg, d_flag);
+        HIP_TRY(c, hipGetLastError());
+        { int rc = scan_u32(c, d_flag, nseg, d_rank, d_sums); if (rc) return rc; }
+        uint32_t inner = 0u;
+        HIP_TRY(c, hipMemcpyAsync(&inner, d_rank + nseg, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (inner == 0u) break;
+        // the partition of every inner range, then its two children
+        hipLaunchKernelGGL(flag_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, (const Rec*)d_recs, (const uint32_t*)d_idx[cur], (const float*)d_cent, d_pass);
+        HIP_TRY(c, hipGetLastError());
+        { int rc = scan_u32(c, d_pass, n, d_P, d_sums); if (rc) return rc; }
+        hipLaunchKernelGGL(pair_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, (const Rec*)d_recs, (const uint32_t*)d_pass, (const uint32_t*)d_P, d_X, d_Y);
+        hipLaunchKernelGGL(move_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, (const Rec*)d_recs, (const uint32_t*)d_pass, (const uint32_t*)d_P,
+                           (const uint32_t*)d_X, (const uint32_t*)d_Y, (const uint32_t*)d_idx[cur], d_idx[cur ^ 1u]);
+        cur ^= 1u;
+        HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, st));
+        hipLaunchKernelGGL(children_kernel, dim3(seg_blocks), dim3(256), 0, st, d_recs, base, nseg, base + nseg, (const uint32_t*)d_rank, (const uint32_t*)d_P, d_counter);
+        hipLaunchKernelGGL(mark_kernel, dim3(pos_blocks), dim3(256), 0, st, n, d_seg, (const Rec*)d_recs);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&nbig, d_counter, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (nbig > big_cap) return fail(c, PTX_ERR_STATE, "ptx_bvh_build: more large ranges than primitives allow");
+        base += nseg;
+        nseg = 2u * inner;
+    }
+    // bvh.rs:188-213: the flat array is the pre-order of the tree
+    for (size_t l = levels.size(); l-- > 0;)
+        hipLaunchKernelGGL(size_kernel, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, st, d_recs, levels[l].first, levels[l].second);
+    for (size_t l = 0; l < levels.size(); l++)
+        hipLaunchKernelGGL(preorder_kernel, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, st, d_recs, levels[l].first, levels[l].second);
+    const uint32_t nrec = base + nseg;
+    hipLaunchKernelGGL(emit_kernel, dim3((nrec + 255u) / 256u), dim3(256), 0, st, (const Rec*)d_recs, nrec, d_nodes);
+    HIP_TRY(c, hipGetLastError());
+    static_assert(sizeof(FlatNode) == sizeof(ptx_bvh_node), "flat node layout");
+    HIP_TRY(c, hipMemcpyAsync(nodes_out, d_nodes, (size_t)nrec * sizeof(FlatNode), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(prim_indices_out, d_idx[cur], (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    *n_nodes_out = nrec;  // every record is a node: the root's subtree size
+    return PTX_OK;
+}
 
 int ptx_post_process(ptx_ctx* c, const ptx_post_params* pp) {
     if (!c || !pp) return PTX_ERR_BAD_ARG;

@@ -111,6 +111,17 @@ class PathTracer:
         self._ck(self.lib.ptx_read_primary_ids(self.h, _p(out)), "ptx_read_primary_ids")
         return out
 
+    def bvh_build(self, aabbs: np.ndarray):
+        """Bvh::build (src/accel/bvh.rs:37-213) on the GPU over n boxes {min xyz, max xyz}: (nodes, primitive order),
+        the arrays the reference's sequential builder gives."""
+        aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
+        n = len(aabbs)
+        nodes = np.zeros(max(1, 2 * n), dtype=NODE_DT)
+        prims = np.zeros(n, dtype=np.uint32)
+        nn = C.c_uint32()
+        self._ck(self.lib.ptx_bvh_build(self.h, _p(aabbs), n, _p(nodes), C.byref(nn), _p(prims)), "ptx_bvh_build")
+        return nodes[: nn.value].copy(), prims
+
     def debug_capture(self, max_samples: int):
         self._ck(self.lib.ptx_debug_capture(self.h, max_samples), "ptx_debug_capture")
 

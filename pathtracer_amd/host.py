@@ -35,6 +35,8 @@ SYMBOLS = [
     ("pth_scene_texture_path", C.c_char_p, [_P, _U]),
     ("pth_scene_provide_texture", C.c_int, [_P, _U, _P, _U, _U]),
     ("pth_scene_build", C.c_int, [_P]),
+    ("pth_bvh_build", C.c_int, [_P, _P, _U, _P, C.POINTER(_U), _P]),
+    ("pth_scene_build_with", C.c_int, [_P, _P, _P]),
     ("pth_scene_figures", _P, [_P, C.POINTER(_U)]),
     ("pth_scene_materials", _P, [_P, C.POINTER(_U)]),
     ("pth_scene_bvh_nodes", _P, [_P, C.POINTER(_U)]),
@@ -175,11 +177,18 @@ class Scene:
         f = lambda v: float("nan") if v is None else float(v)
         self.lib.pth_scene_set_render_settings(self.h, u(max_bounces), u(fractal_march_steps), u(tone_mapper), f(firefly_clamp), f(exposure))
 
-    def build(self, decode_textures: bool = True) -> "Scene":
+    def build(self, decode_textures: bool = True, tracer=None) -> "Scene":
+        """pth_scene_build; with a device.PathTracer as `tracer` the BVH is built on that GPU (ptx_bvh_build),
+        which gives the same node and primitive arrays as the host builder."""
         if decode_textures:
             self.provide_textures()
-        if self.lib.pth_scene_build(self.h) != 0:
-            raise RuntimeError("pth_scene_build failed")
+        if tracer is None:
+            rc = self.lib.pth_scene_build(self.h)
+        else:
+            fn = C.cast(tracer.lib.ptx_bvh_build, _P)
+            rc = self.lib.pth_scene_build_with(self.h, fn, tracer.h)
+        if rc != 0:
+            raise RuntimeError(f"pth_scene_build failed: {self.lib.pth_last_error(self.h).decode()}")
         self.built = True
         return self
 
@@ -219,6 +228,19 @@ class Scene:
         for p, k in zip(ptrs, n):
             args += [C.c_void_p(p), k.value]
         tracer._ck(tracer.lib.ptx_upload_scene(tracer.h, *args), "ptx_upload_scene")
+
+
+def bvh_build(aabbs: np.ndarray):
+    """Bvh::build (src/accel/bvh.rs:37-213) on the host over n boxes {min xyz, max xyz}: (nodes, primitive order)."""
+    aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
+    n = len(aabbs)
+    nodes = np.zeros(max(1, 2 * n), dtype=NODE_DT)
+    prims = np.zeros(n, dtype=np.uint32)
+    nn = _U()
+    rc = load().pth_bvh_build(None, aabbs.ctypes.data_as(_P), n, nodes.ctypes.data_as(_P), C.byref(nn), prims.ctypes.data_as(_P))
+    if rc != 0:
+        raise RuntimeError(f"pth_bvh_build failed ({rc})")
+    return nodes[: nn.value].copy(), prims
 
 
 class Accumulator:
