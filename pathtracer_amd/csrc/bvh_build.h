@@ -13,9 +13,9 @@
 //    Two prefix sums give every element its destination;
 //  * the flat array is the pre-order of the tree (bvh.rs:188-213): subtree sizes bottom-up, indices top-down.
 //
-// Work per level: ranges of at most 256 primitives are handled by one wave each (bounds, bins in LDS, split);
-// larger ranges by one lane per primitive with wave-aggregated atomics and bins privatised in LDS per
-// workgroup.  All of it is HBM-bound integer / min-max work: per level ~10 passes over 4-36 B per primitive.
+// Work per level: ranges of at most 256 primitives are handled by one wave each (bounds, bins in LDS, split
+// search with one lane per candidate); larger ranges by workgroups that walk contiguous chunks of positions and
+// keep the bounds / bins of the range they are in private until the range changes.  All of it is HBM-bound integer / min-max work: per level ~10 passes over 4-36 B per primitive.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -51,6 +51,17 @@ __device__ inline void amin_f(float* a, float v) {
 __device__ inline void amax_f(float* a, float v) {
     v = v + 0.0f;
     if (v >= 0.0f) atomicMax((int*)a, __float_as_int(v)); else atomicMin((unsigned int*)a, __float_as_uint(v));
+}
+// Waits until this wave's LDS operations have completed (s_waitcnt lgkmcnt(0)).  The compiler puts no such wait
+// between LDS atomics that return nothing and a following workgroup barrier; measured on gfx950, a read after the
+// barrier can then overtake an atomic that many lanes aim at one address (counts came out short), so every
+// "atomics, then barrier, then read" below drains first.
+__device__ inline void lds_drain() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+// Orders the LDS operations of one wave's lanes against each other.
+__device__ inline void wave_sync() {
+    lds_drain();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 __device__ inline float wave_min_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64)); return v; }
 __device__ inline float wave_max_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
@@ -120,6 +131,49 @@ __device__ inline void find_split(const uint32_t* bins, const float* pmn, const 
     }
 }
 
+// find_split with one lane per candidate (axis, boundary): lane = axis * (NB - 1) + i evaluates the split after
+// bin i.  min / max and the integer counts do not depend on the order of the sweep, the cost expression is the
+// reference's, and the sequential search keeps the FIRST candidate that reaches the lowest cost, which is the
+// lowest lane among equal costs.  A cost that is not below +inf (or is a NaN) is never taken, as in the loop.
+__device__ inline void find_split_wave(const uint32_t* bins, const float* pmn, const float* pmx, uint32_t lane, uint32_t& best_axis, float& best_split) {
+    const float INF = __uint_as_float(POS_INF);
+    float cost = INF, split = 0.0f;
+    if (lane < 3u * (NB - 1)) {
+        const int axis = (int)lane / (NB - 1), i = (int)lane % (NB - 1);
+        const float mn = pmn[axis], extent = pmx[axis] - mn;
+        if (!(fabsf(extent) < 1e-8f)) {
+            const float* bb = (const float*)(bins + axis * NB * 6);
+            const uint32_t* bc = bins + 3 * NB * 6 + axis * NB;
+            float lmn[3] = {INF, INF, INF}, lmx[3] = {-INF, -INF, -INF}, rmn[3] = {INF, INF, INF}, rmx[3] = {-INF, -INF, -INF};
+            uint32_t lc = 0u, rc = 0u;
+            for (int b = 0; b < NB; b++) {
+                const bool left = b <= i;
+                for (int k = 0; k < 3; k++) {
+                    const float lo = bb[b * 6 + k], hi = bb[b * 6 + 3 + k];
+                    if (left) { lmn[k] = fminf(lmn[k], lo); lmx[k] = fmaxf(lmx[k], hi); }
+                    else { rmn[k] = fminf(rmn[k], lo); rmx[k] = fmaxf(rmx[k], hi); }
+                }
+                if (left) lc += bc[b]; else rc += bc[b];
+            }
+            if (lc != 0u && rc != 0u) {
+                const float c = (float)lc * surface_area(lmn, lmx) + (float)rc * surface_area(rmn, rmx);
+                if (c < INF) cost = c;
+                const float bin_width = extent / (float)NB;
+                split = mn + (float)(i + 1) * bin_width;
+            }
+        }
+    }
+    uint32_t who = cost < INF ? lane : 64u;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oc = __shfl_xor(cost, o, 64);
+        const uint32_t ow = (uint32_t)__shfl_xor((int)who, o, 64);
+        if (oc < cost || (oc == cost && ow < who)) { cost = oc; who = ow; }
+    }
+    if (who >= 64u) { best_axis = 0u; best_split = 0.0f; return; }
+    best_axis = who / (uint32_t)(NB - 1);
+    best_split = __shfl(split, (int)who, 64);
+}
+
 // ---- per level, ranges of at most SMALL_MAX primitives: one wave each ----------------------------------------------
 __global__ void __launch_bounds__(256) seg_small_kernel(Rec* recs, uint32_t base, uint32_t nseg, const uint32_t* idx,
                                                         const float* aabb, const float* cent) {
@@ -140,91 +194,160 @@ __global__ void __launch_bounds__(256) seg_small_kernel(Rec* recs, uint32_t base
     for (int a = 0; a < 3; a++) { mn[a] = wave_min_f(mn[a]); mx[a] = wave_max_f(mx[a]); }
     const bool inner = mine && count > LEAF_MAX;
     uint32_t* bins = lds_bins[wave];
-    bins_clear(bins, lane, 64u);
-    __syncthreads();
-    if (inner)
+    // a wave owns its bins: its LDS operations complete in order, no workgroup barrier is needed
+    uint32_t axis = 0u;
+    float split = 0.0f;
+    if (inner) {
+        bins_clear(bins, lane, 64u);
+        wave_sync();
         for (uint32_t k = start + lane; k < end; k += 64u) {
             const uint32_t p = idx[k];
             bin_add(bins, mn, mx, aabb + (size_t)p * 6, cent + (size_t)p * 3);
         }
-    __syncthreads();
+        wave_sync();
+        find_split_wave(bins, mn, mx, lane, axis, split);
+    }
     if (mine && lane == 0u) {
         for (int a = 0; a < 3; a++) { r->mn[a] = mn[a]; r->mx[a] = mx[a]; }
         if (inner) {
-            uint32_t axis;
-            float split;
-            find_split(bins, mn, mx, axis, split);
             r->axis = axis;
             r->split = split;
         }
     }
 }
 
-// ---- per level, larger ranges: one lane per primitive ---------------------------------------------------------------
-__global__ void __launch_bounds__(256) bounds_big_kernel(uint32_t n, const uint32_t* seg_of, Rec* recs, const uint32_t* idx, const float* aabb) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t seg = i < n ? seg_of[i] : NONE;
-    if (seg != NONE && recs[seg].end - recs[seg].start <= SMALL_MAX) seg = NONE;
+// ---- per level, larger ranges ----------------------------------------------------------------------------------------
+// Every workgroup walks a contiguous chunk of positions in tiles of 256.  Ranges are contiguous, so a tile whose
+// first and last position lie in one range lies in it entirely; while consecutive tiles stay in one range the
+// workgroup accumulates privately (registers for the bounds, LDS for the bins) and touches the range's record
+// once, when the range changes or the chunk ends.  Tiles across a range boundary go to the record directly.
+__device__ inline bool is_big(const Rec& r) { return r.end - r.start > SMALL_MAX; }
+
+__global__ void __launch_bounds__(256) bounds_big_kernel(uint32_t n, uint32_t chunk, const uint32_t* seg_of, Rec* recs, const uint32_t* idx, const float* aabb) {
+    __shared__ float red[6];
     const float INF = __uint_as_float(POS_INF);
+    const uint32_t c0 = blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+    uint32_t cur = NONE;
     float mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
-    if (seg != NONE) {
-        const float* b = aabb + (size_t)idx[i] * 6;
-        for (int a = 0; a < 3; a++) { mn[a] = b[a]; mx[a] = b[3 + a]; }
-    }
-    const uint32_t first = (uint32_t)__shfl((int)seg, 0, 64);
-    if (__all(seg == first)) {  // the usual case: the whole wave lies in one range (or in none)
-        if (first == NONE) return;
-        for (int a = 0; a < 3; a++) { mn[a] = wave_min_f(mn[a]); mx[a] = wave_max_f(mx[a]); }
-        if ((threadIdx.x & 63u) == 0u)
-            for (int a = 0; a < 3; a++) { amin_f(&recs[seg].mn[a], mn[a]); amax_f(&recs[seg].mx[a], mx[a]); }
-    } else if (seg != NONE) {
-        for (int a = 0; a < 3; a++) { amin_f(&recs[seg].mn[a], mn[a]); amax_f(&recs[seg].mx[a], mx[a]); }
+    for (uint32_t t0 = c0;; t0 += 256u) {
+        const bool done = t0 >= c1;
+        uint32_t sa = NONE;
+        bool uni = false;
+        if (!done) {
+            const uint32_t last = t0 + 255u < c1 ? t0 + 255u : c1 - 1u;
+            sa = seg_of[t0];
+            uni = sa != NONE && sa == seg_of[last] && is_big(recs[sa]);
+        }
+        if (cur != NONE && !(uni && sa == cur)) {  // the private bounds go to the record (every lane takes this branch together)
+            if (threadIdx.x < 6u) red[threadIdx.x] = threadIdx.x < 3u ? INF : -INF;
+            lds_drain();
+            __syncthreads();
+            for (int a = 0; a < 3; a++) { mn[a] = wave_min_f(mn[a]); mx[a] = wave_max_f(mx[a]); }
+            if ((threadIdx.x & 63u) == 0u)
+                for (int a = 0; a < 3; a++) { amin_f(&red[a], mn[a]); amax_f(&red[3 + a], mx[a]); }
+            lds_drain();
+            __syncthreads();
+            if (threadIdx.x < 3u) amin_f(&recs[cur].mn[threadIdx.x], red[threadIdx.x]);
+            else if (threadIdx.x < 6u) amax_f(&recs[cur].mx[threadIdx.x - 3u], red[threadIdx.x]);
+            lds_drain();
+            __syncthreads();
+            for (int a = 0; a < 3; a++) { mn[a] = INF; mx[a] = -INF; }
+            cur = NONE;
+        }
+        if (done) break;
+        const uint32_t i = t0 + threadIdx.x;
+        if (uni) {
+            cur = sa;
+            if (i < c1) {
+                const float* b = aabb + (size_t)idx[i] * 6;
+                for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], b[a]); mx[a] = fmaxf(mx[a], b[3 + a]); }
+            }
+        } else {
+            uint32_t seg = i < c1 ? seg_of[i] : NONE;
+            if (seg != NONE && !is_big(recs[seg])) seg = NONE;
+            float bn[3] = {INF, INF, INF}, bx[3] = {-INF, -INF, -INF};
+            if (seg != NONE) {
+                const float* b = aabb + (size_t)idx[i] * 6;
+                for (int a = 0; a < 3; a++) { bn[a] = b[a]; bx[a] = b[3 + a]; }
+            }
+            const uint32_t first = (uint32_t)__shfl((int)seg, 0, 64);
+            if (__all(seg == first)) {
+                if (first != NONE) {
+                    for (int a = 0; a < 3; a++) { bn[a] = wave_min_f(bn[a]); bx[a] = wave_max_f(bx[a]); }
+                    if ((threadIdx.x & 63u) == 0u)
+                        for (int a = 0; a < 3; a++) { amin_f(&recs[seg].mn[a], bn[a]); amax_f(&recs[seg].mx[a], bx[a]); }
+                }
+            } else if (seg != NONE) {
+                for (int a = 0; a < 3; a++) { amin_f(&recs[seg].mn[a], bn[a]); amax_f(&recs[seg].mx[a], bx[a]); }
+            }
+        }
     }
 }
 __global__ void __launch_bounds__(256) bins_clear_kernel(uint32_t* bins, uint32_t nslots) {
     const uint32_t slot = blockIdx.x;
     if (slot < nslots) bins_clear(bins + (size_t)slot * BIN_WORDS, threadIdx.x, 256u);
 }
-__global__ void __launch_bounds__(256) bins_big_kernel(uint32_t n, const uint32_t* seg_of, const Rec* recs, const uint32_t* idx,
+__global__ void __launch_bounds__(256) bins_big_kernel(uint32_t n, uint32_t chunk, const uint32_t* seg_of, const Rec* recs, const uint32_t* idx,
                                                        const float* aabb, const float* cent, uint32_t* bins) {
     __shared__ uint32_t lds_bins[BIN_WORDS];
-    const uint32_t i0 = blockIdx.x * 256u, i = i0 + threadIdx.x;
-    const uint32_t last = i0 + 255u < n ? i0 + 255u : n - 1u;
-    uint32_t seg = i < n ? seg_of[i] : NONE;
-    if (seg != NONE && recs[seg].end - recs[seg].start <= SMALL_MAX) seg = NONE;
-    // ranges are contiguous: the workgroup lies in one range when its first and last positions do
-    const uint32_t sa = seg_of[i0], sb = seg_of[last];
-    const bool uniform = sa == sb && sa != NONE && recs[sa].end - recs[sa].start > SMALL_MAX;
-    if (uniform) {
-        bins_clear(lds_bins, threadIdx.x, 256u);
-        __syncthreads();
-        if (seg != NONE) {
-            const Rec& r = recs[seg];
-            const uint32_t p = idx[i];
-            bin_add(lds_bins, r.mn, r.mx, aabb + (size_t)p * 6, cent + (size_t)p * 3);
+    const uint32_t c0 = blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+    uint32_t cur = NONE;
+    for (uint32_t t0 = c0;; t0 += 256u) {
+        const bool done = t0 >= c1;
+        uint32_t sa = NONE;
+        bool uni = false;
+        if (!done) {
+            const uint32_t last = t0 + 255u < c1 ? t0 + 255u : c1 - 1u;
+            sa = seg_of[t0];
+            uni = sa != NONE && sa == seg_of[last] && is_big(recs[sa]);
         }
-        __syncthreads();
-        uint32_t* g = bins + (size_t)recs[sa].bin_slot * BIN_WORDS;
-        for (uint32_t w = threadIdx.x; w < 3u * NB; w += 256u) {  // one lane per (axis, bin)
-            const uint32_t c = lds_bins[3 * NB * 6 + w];
-            if (c == 0u) continue;
-            float* f = (float*)(g + w * 6u);
-            const float* l = (const float*)(lds_bins + w * 6u);
-            amin_f(f + 0, l[0]); amin_f(f + 1, l[1]); amin_f(f + 2, l[2]);
-            amax_f(f + 3, l[3]); amax_f(f + 4, l[4]); amax_f(f + 5, l[5]);
-            atomicAdd(g + 3 * NB * 6 + w, c);
+        if (cur != NONE && !(uni && sa == cur)) {  // the private bins go to the range's bins
+            lds_drain();
+            __syncthreads();
+            uint32_t* g = bins + (size_t)recs[cur].bin_slot * BIN_WORDS;
+            for (uint32_t w = threadIdx.x; w < 3u * NB; w += 256u) {  // one lane per (axis, bin)
+                const uint32_t c = lds_bins[3 * NB * 6 + w];
+                if (c == 0u) continue;
+                float* f = (float*)(g + w * 6u);
+                const float* l = (const float*)(lds_bins + w * 6u);
+                amin_f(f + 0, l[0]); amin_f(f + 1, l[1]); amin_f(f + 2, l[2]);
+                amax_f(f + 3, l[3]); amax_f(f + 4, l[4]); amax_f(f + 5, l[5]);
+                atomicAdd(g + 3 * NB * 6 + w, c);
+            }
+            lds_drain();
+            __syncthreads();
+            cur = NONE;
         }
-    } else if (seg != NONE) {
-        const Rec& r = recs[seg];
-        const uint32_t p = idx[i];
-        bin_add(bins + (size_t)r.bin_slot * BIN_WORDS, r.mn, r.mx, aabb + (size_t)p * 6, cent + (size_t)p * 3);
+        if (done) break;
+        const uint32_t i = t0 + threadIdx.x;
+        if (uni) {
+            if (cur == NONE) {
+                bins_clear(lds_bins, threadIdx.x, 256u);
+                lds_drain();
+                __syncthreads();
+                cur = sa;
+            }
+            if (i < c1) {
+                const Rec& r = recs[sa];
+                const uint32_t p = idx[i];
+                bin_add(lds_bins, r.mn, r.mx, aabb + (size_t)p * 6, cent + (size_t)p * 3);
+            }
+        } else {
+            uint32_t seg = i < c1 ? seg_of[i] : NONE;
+            if (seg != NONE && !is_big(recs[seg])) seg = NONE;
+            if (seg != NONE) {
+                const Rec& r = recs[seg];
+                const uint32_t p = idx[i];
+                bin_add(bins + (size_t)r.bin_slot * BIN_WORDS, r.mn, r.mx, aabb + (size_t)p * 6, cent + (size_t)p * 3);
+            }
+        }
     }
 }
 __global__ void __launch_bounds__(256) split_big_kernel(Rec* recs, uint32_t base, uint32_t nseg, const uint32_t* bins) {
     const uint32_t s_i = blockIdx.x * 256u + threadIdx.x;
     if (s_i >= nseg) return;
     Rec* r = recs + base + s_i;
-    if (r->end - r->start <= SMALL_MAX) return;
+    if (!is_big(*r)) return;
     uint32_t axis;
     float split;
     find_split(bins + (size_t)r->bin_slot * BIN_WORDS, r->mn, r->mx, axis, split);
@@ -367,15 +490,19 @@ __device__ inline uint32_t block_exclusive(uint32_t v, uint32_t* total) {
     __shared__ uint32_t sh[256];
     const uint32_t t = threadIdx.x;
     sh[t] = v;
+    lds_drain();
     __syncthreads();
     for (uint32_t o = 1u; o < 256u; o <<= 1) {
         uint32_t add = t >= o ? sh[t - o] : 0u;
+        lds_drain();
         __syncthreads();
         sh[t] += add;
+        lds_drain();
         __syncthreads();
     }
     const uint32_t incl = sh[t];
     if (total) *total = sh[255];
+    lds_drain();
     __syncthreads();
     return incl - v;
 }

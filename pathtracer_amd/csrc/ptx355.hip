@@ -1241,6 +1241,10 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
     HIP_TRY(c, mem.alloc((void**)&d_nodes, (size_t)n * 2 * sizeof(FlatNode)));
     hipStream_t st = c->stream;
     const uint32_t pos_blocks = (n + 255u) / 256u;
+    // the chunked kernels: at most 2048 workgroups, chunks a whole number of 256-position tiles
+    const uint32_t chunk_blocks = pos_blocks < 2048u ? pos_blocks : 2048u;
+    const uint32_t chunk = ((pos_blocks + chunk_blocks - 1u) / chunk_blocks) * 256u;
+    const uint32_t chunk_grid = (n + chunk - 1u) / chunk;
     HIP_TRY(c, hipMemcpyAsync(d_aabb, aabbs, (size_t)n * 24, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(d_counter, 0, 8, st));
     hipLaunchKernelGGL(prep_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const float*)d_aabb, d_cent, d_idx[0], d_seg, d_counter + 1);
@@ -1258,9 +1262,9 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
         const uint32_t seg_blocks = (nseg + 255u) / 256u;
         // bounds of every range of the level; bins and the split of its inner ranges
         if (nbig > 0u) {
-            hipLaunchKernelGGL(bounds_big_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, d_recs, (const uint32_t*)d_idx[cur], (const float*)d_aabb);
+            hipLaunchKernelGGL(bounds_big_kernel, dim3(chunk_grid), dim3(256), 0, st, n, chunk, (const uint32_t*)d_seg, d_recs, (const uint32_t*)d_idx[cur], (const float*)d_aabb);
             hipLaunchKernelGGL(bins_clear_kernel, dim3(nbig), dim3(256), 0, st, d_bins, nbig);
-            hipLaunchKernelGGL(bins_big_kernel, dim3(pos_blocks), dim3(256), 0, st, n, (const uint32_t*)d_seg, (const Rec*)d_recs, (const uint32_t*)d_idx[cur],
+            hipLaunchKernelGGL(bins_big_kernel, dim3(chunk_grid), dim3(256), 0, st, n, chunk, (const uint32_t*)d_seg, (const Rec*)d_recs, (const uint32_t*)d_idx[cur],
                                (const float*)d_aabb, (const float*)d_cent, d_bins);
             hipLaunchKernelGGL(split_big_kernel, dim3(seg_blocks), dim3(256), 0, st, d_recs, base, nseg, (const uint32_t*)d_bins);
         }

@@ -45,6 +45,26 @@ def main():
     nodes = db["nodes"]
     leaves = nodes[nodes["prim_count"] > 0]
     out["leaves"] = int(len(leaves))
+    figs = db["figs"]
+    tri = figs[figs["shape_type"] == 7]
+    v = np.stack([tri["v0"], tri["v1"], tri["v2"]], axis=1)
+    mn, mx = v.min(axis=1), v.max(axis=1)
+    flat = (mx - mn) < np.float32(1e-4)   # aabb.rs:69-81
+    boxes = np.concatenate([np.where(flat, mn - np.float32(1e-4), mn), np.where(flat, mx + np.float32(1e-4), mx)], axis=1).astype(np.float32)
+    del v, mn, mx, flat
+    alone = []
+    for _ in range(args.repeat):
+        t0 = time.perf_counter()
+        gn, gp = pt.bvh_build(boxes)
+        alone.append(time.perf_counter() - t0)
+    out["triangle_boxes"] = int(len(boxes))
+    out["ptx_bvh_build_s"] = [round(t, 4) for t in alone]
+    if not args.skip_host:
+        t0 = time.perf_counter()
+        hn, hp_ = host.bvh_build(boxes)
+        out["pth_bvh_build_s"] = round(time.perf_counter() - t0, 4)
+        out["builders_identical_on_triangle_boxes"] = bool(len(hn) == len(gn) and (hp_ == gp).all() and all(
+            (hn[k] == gn[k]).all() for k in ("aabb_min", "aabb_max", "left_or_prim", "prim_count")))
     if not args.skip_host:
         hs = scene()
         t0 = time.perf_counter()
