@@ -88,6 +88,39 @@ __device__ inline void bin_add(uint32_t* bins, const float* pmn, const float* pm
         atomicAdd(bins + 3 * NB * 6 + axis * NB + b, 1u);
     }
 }
+// The same for a whole wave whose lanes lie in one range (`valid` lanes hold a primitive; every lane calls).  Where
+// all the wave's primitives fall into one bin of an axis - the rule near the top of a tree over primitives that
+// arrive in spatial order - the wave combines them first and touches the bin once instead of 64 times.
+__device__ inline void bin_add_wave(uint32_t* bins, const float* pmn, const float* pmx, bool valid, const float* box, const float* cen) {
+    const float INF = __uint_as_float(POS_INF);
+    const unsigned long long live = __ballot(valid);
+    if (live == 0ull) return;
+    const int leader = __ffsll((long long)live) - 1;
+    float bx[6];
+    for (int k = 0; k < 6; k++) bx[k] = valid ? box[k] : (k < 3 ? INF : -INF);
+    for (int axis = 0; axis < 3; axis++) {
+        float extent = pmx[axis] - pmn[axis];
+        if (fabsf(extent) < 1e-8f) continue;  // the same for every lane
+        float inv_extent = (float)NB / extent;
+        const int b = valid ? bin_of(cen[axis], pmn[axis], inv_extent) : -1;
+        const int b0 = __shfl(b, leader, 64);
+        if (__ballot(valid && b != b0) == 0ull) {
+            float r[6];
+            for (int k = 0; k < 3; k++) { r[k] = wave_min_f(bx[k]); r[3 + k] = wave_max_f(bx[3 + k]); }
+            if ((int)(threadIdx.x & 63u) == leader) {
+                float* f = (float*)(bins + (axis * NB + b0) * 6);
+                amin_f(f + 0, r[0]); amin_f(f + 1, r[1]); amin_f(f + 2, r[2]);
+                amax_f(f + 3, r[3]); amax_f(f + 4, r[4]); amax_f(f + 5, r[5]);
+                atomicAdd(bins + 3 * NB * 6 + axis * NB + b0, (uint32_t)__popcll(live));
+            }
+        } else if (valid) {
+            float* f = (float*)(bins + (axis * NB + b) * 6);
+            amin_f(f + 0, box[0]); amin_f(f + 1, box[1]); amin_f(f + 2, box[2]);
+            amax_f(f + 3, box[3]); amax_f(f + 4, box[4]); amax_f(f + 5, box[5]);
+            atomicAdd(bins + 3 * NB * 6 + axis * NB + b, 1u);
+        }
+    }
+}
 __device__ inline void bins_clear(uint32_t* bins, uint32_t lane, uint32_t stride) {
     for (uint32_t w = lane; w < BIN_WORDS; w += stride)
         bins[w] = w >= 3u * NB * 6u ? 0u : ((w % 6u) < 3u ? POS_INF : NEG_INF);
@@ -327,11 +360,9 @@ __global__ void __launch_bounds__(256) bins_big_kernel(uint32_t n, uint32_t chun
                 __syncthreads();
                 cur = sa;
             }
-            if (i < c1) {
-                const Rec& r = recs[sa];
-                const uint32_t p = idx[i];
-                bin_add(lds_bins, r.mn, r.mx, aabb + (size_t)p * 6, cent + (size_t)p * 3);
-            }
+            const Rec& r = recs[sa];
+            const uint32_t p = i < c1 ? idx[i] : 0u;
+            bin_add_wave(lds_bins, r.mn, r.mx, i < c1, aabb + (size_t)p * 6, cent + (size_t)p * 3);
         } else {
             uint32_t seg = i < c1 ? seg_of[i] : NONE;
             if (seg != NONE && !is_big(recs[seg])) seg = NONE;

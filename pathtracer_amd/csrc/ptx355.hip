@@ -16,12 +16,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <chrono>
 #include <vector>
 #include "sched_dev.h"
 #include "post_dev.h"
 #include "bvh_build.h"
 
 #define PTX_BLOCK 256
+#define PT_DEEP_TREE 20u  // stack entries from which a tree counts as deep (millions of primitives): one node visit per WALK step
 #define PTX_WAVES_PER_BLOCK 4
 #define PT_PIXEL_FIELDS 9u  // per-lane LDS slots: mean xyz, M2 xyz, sample index, path-bounces, primary id
 #ifndef PTX_CLAIM_LDS
@@ -263,22 +265,27 @@ PT_DEV void sched_body(const TraceParams& P) {
         uint32_t live = 0u, fullest = LS_IDLE, fullest_n = 0u, march = LS_IDLE, march_n = 0u;
 #pragma unroll
         for (uint32_t s = LS_WALK; s < (uint32_t)LS_COUNT; s++) {
-            pop[s] = (!FRAC && s >= (uint32_t)LS_MANDEL) ? 0u : (uint32_t)__popcll(__ballot(S == s));
+            pop[s] = (!FRAC && (s == (uint32_t)LS_MANDEL || s == (uint32_t)LS_JULIA)) ? 0u : (uint32_t)__popcll(__ballot(S == s));
             live += pop[s];
             if (pop[s] > fullest_n) { fullest_n = pop[s]; fullest = s; }
-            if (s >= (uint32_t)LS_TORUS && pop[s] > march_n) { march_n = pop[s]; march = s; }
+            if (s >= (uint32_t)LS_TORUS && s <= (uint32_t)LS_JULIA && pop[s] > march_n) { march_n = pop[s]; march = s; }
         }
         if (live == 0u) break;
+        const bool single = P.walk_single != 0u;
         uint32_t pick = fullest;
-        if (pop[LS_WALK] * P.share_walk >= live) pick = LS_WALK;
+        if (pop[LS_LEAF] * P.share_leaf >= live) pick = LS_LEAF;
+        else if (pop[LS_WALK] * P.share_walk >= live) pick = LS_WALK;
         else if (pop[LS_POST] * P.share_post >= live) pick = LS_POST;
         else if (march_n * P.share_march >= live) pick = march;
         if (pick == LS_WALK) {
             for (;;) {
-                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, P.walk_single != 0u, frac);
+                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, single, frac);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
                 if (w == 0u || w * P.share_walk < live) break;
+                if (single && (uint32_t)__popcll(__ballot(S == LS_LEAF)) * P.share_leaf >= live) break;
             }
+        } else if (pick == LS_LEAF) {
+            if (S == LS_LEAF) S = leaf_step<FRAC>(sc, tv, P.cam.fractal_march_steps, single, frac);
         } else if (pick == LS_POST) {
             if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
         } else {
@@ -293,8 +300,8 @@ PT_DEV void sched_body(const TraceParams& P) {
                     PT_SITE_ADD(73, (uint32_t)__popcll(__ballot(S == LS_JULIA)));
                     PT_SITE_ADD(74, (uint32_t)__popcll(__ballot(S == LS_IDLE)));
                 }
-                if (S == pick) S = (FRAC && pick >= (uint32_t)LS_MANDEL) ? frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park)
-                                                                        : march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps);
+                if (S == pick) S = (FRAC && pick >= (uint32_t)LS_MANDEL) ? frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park, single)
+                                                                        : march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
                 if (m == 0u || m * 4u < n0 * 3u) break;
             }
@@ -518,6 +525,7 @@ struct ptx_ctx {
     unsigned long long* stats = nullptr;
     bool sched = false;           // the uploaded scene runs the wave-scheduled kernels
     uint32_t shares[3] = {4u, 2u, 4u};  // their scheduling shares (walk, post, march)
+    uint32_t share_leaf = 4u;           // and the share of lanes at leaf primitives (one-visit-per-step mode)
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
     bool split = true;            // scheduled fractal kernels: sample-granular jobs + fold (PTX355_SPLIT=0 turns it off)
@@ -909,16 +917,26 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     c->sched = pick_sched(sc, dprims);
     {
         const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {4u, 2u, 4u};
+        // deep trees (one node visit per step, lanes at leaf primitives served as a state of their own): walk, post, march, leaf
+        const uint32_t deep_mesh[4] = {12u, 2u, 4u, 4u}, deep_mixed[4] = {4u, 2u, 16u, 6u};
         bool marchers = false;
         for (const DPrim& g : dprims) marchers = marchers || g.type == FIG_TORUS || g.type == FIG_MEBIUS || g.type == FIG_MANDELBULB || g.type == FIG_JULIA;
         const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
+        c->share_leaf = 4u;
+        if (sc.stack_entries >= PT_DEEP_TREE) {
+            pick = marchers ? deep_mixed : deep_mesh;
+            c->share_leaf = pick[3];
+        }
         memcpy(c->shares, pick, sizeof(c->shares));
         c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
         if (const char* e = getenv("PTX355_CLAIM_TILE")) c->claim_tile = atoi(e) > 1 ? 64u : 1u;
         if (const char* e = getenv("PTX355_SPLIT")) c->split = e[0] != '0';
         if (const char* e = getenv("PTX355_SHARES")) {  // measurement runs: "walk,post,march"
             unsigned w = 0, p = 0, m = 0;
-            if (sscanf(e, "%u,%u,%u", &w, &p, &m) == 3 && w && p && m) { c->shares[0] = w; c->shares[1] = p; c->shares[2] = m; }
+            unsigned l = 0;
+            const int got = sscanf(e, "%u,%u,%u,%u", &w, &p, &m, &l);
+            if (got >= 3 && w && p && m) { c->shares[0] = w; c->shares[1] = p; c->shares[2] = m; }
+            if (got == 4 && l) c->share_leaf = l;
         }
     }
     return PTX_OK;
@@ -1031,7 +1049,9 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
-        P.walk_single = c->sc.stack_entries >= 20u ? 1u : 0u;  // trees deeper than ~20 levels (millions of primitives)
+        P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
+        if (const char* e = getenv("PTX355_WALK_SINGLE")) P.walk_single = e[0] != '0' ? 1u : 0u;  // measurement and test runs
+        P.share_leaf = c->share_leaf;
     }
     // Fractal scenes: a pixel on a fractal's silhouette costs hundreds of times a background pixel, and with one
     // lane folding all n samples of its pixel the launch ends on a few lanes finishing theirs.  There the jobs
@@ -1190,7 +1210,8 @@ extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
 namespace {
 struct DevBufs {  // device allocations of one build, released on every exit path
     std::vector<void*> ptrs;
-    ~DevBufs() { for (void* p : ptrs) (void)hipFree(p); }
+    ~DevBufs() { release(); }
+    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
     hipError_t alloc(void** out, size_t bytes) {
         hipError_t e = hipMalloc(out, bytes ? bytes : 4);
         if (e == hipSuccess) ptrs.push_back(*out);
@@ -1217,6 +1238,11 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
     if (n > 0x3FFFFFFFu) return fail(c, PTX_ERR_BAD_ARG, "ptx_bvh_build: more than 2^30 primitives");
     HIP_TRY(c, hipSetDevice(c->device));
     using namespace bvhb;
+    // PTX355_BVH_TIMING=1: wall time of the phases on stderr (measurement runs)
+    const bool timing = getenv("PTX355_BVH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    const auto t_start = now();
     DevBufs mem;
     float *d_aabb, *d_cent;
     uint32_t *d_idx[2], *d_seg, *d_pass, *d_P, *d_X, *d_Y, *d_flag, *d_rank, *d_sums, *d_bins, *d_counter;
@@ -1240,6 +1266,7 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
     HIP_TRY(c, mem.alloc((void**)&d_recs, (size_t)n * 2 * sizeof(Rec)));
     HIP_TRY(c, mem.alloc((void**)&d_nodes, (size_t)n * 2 * sizeof(FlatNode)));
     hipStream_t st = c->stream;
+    const double ms_alloc = ms_since(t_start);
     const uint32_t pos_blocks = (n + 255u) / 256u;
     // the chunked kernels: at most 2048 workgroups, chunks a whole number of 256-position tiles
     const uint32_t chunk_blocks = pos_blocks < 2048u ? pos_blocks : 2048u;
@@ -1254,6 +1281,7 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
     HIP_TRY(c, hipMemcpyAsync(&has_nan, d_counter + 1, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (has_nan) return fail(c, PTX_ERR_BAD_ARG, "ptx_bvh_build: a box holds a NaN");
+    const double ms_in = ms_since(t_start);
     std::vector<std::pair<uint32_t, uint32_t>> levels;  // {first record, records} per level
     uint32_t base = 0u, nseg = 1u, nbig = n > SMALL_MAX ? 1u : 0u, cur = 0u;
     for (;;) {
@@ -1294,6 +1322,7 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
         base += nseg;
         nseg = 2u * inner;
     }
+    const double ms_levels = ms_since(t_start);
     // bvh.rs:188-213: the flat array is the pre-order of the tree
     for (size_t l = levels.size(); l-- > 0;)
         hipLaunchKernelGGL(size_kernel, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, st, d_recs, levels[l].first, levels[l].second);
@@ -1303,10 +1332,18 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
     hipLaunchKernelGGL(emit_kernel, dim3((nrec + 255u) / 256u), dim3(256), 0, st, (const Rec*)d_recs, nrec, d_nodes);
     HIP_TRY(c, hipGetLastError());
     static_assert(sizeof(FlatNode) == sizeof(ptx_bvh_node), "flat node layout");
+    if (timing) HIP_TRY(c, hipStreamSynchronize(st));
+    const double ms_flat = ms_since(t_start);
     HIP_TRY(c, hipMemcpyAsync(nodes_out, d_nodes, (size_t)nrec * sizeof(FlatNode), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(prim_indices_out, d_idx[cur], (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     *n_nodes_out = nrec;  // every record is a node: the root's subtree size
+    if (timing) {
+        const double ms_out = ms_since(t_start);
+        mem.release();
+        fprintf(stderr, "ptx_bvh_build: n %u, %zu levels, %u nodes; ms: alloc %.1f, boxes in %.1f, levels %.1f, flatten %.1f, arrays out %.1f, free %.1f\n",
+                n, levels.size(), nrec, ms_alloc, ms_in - ms_alloc, ms_levels - ms_in, ms_flat - ms_levels, ms_out - ms_flat, ms_since(t_start) - ms_out);
+    }
     return PTX_OK;
 }
 

@@ -39,6 +39,7 @@ struct TraceParams {
     uint32_t total_jobs;    // n_blocks * 256
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
     uint32_t walk_single;   // scheduled kernels: one node visit per WALK step (deep trees)
+    uint32_t share_leaf;    // walk_single: lanes at a leaf primitive are served together from 1/share of the live lanes
     // Sample-granular jobs (scheduled fractal kernels, split_n > 0): job j is sample j % split_n of pixel job
     // j / split_n; a finished sample's radiance goes to staging[sample * frame_pixels + pixel] and the fold
     // kernel folds the samples of each pixel into its running mean in sample order afterwards.
@@ -46,7 +47,8 @@ struct TraceParams {
     float4* staging;
 };
 
-enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS = 4, LS_MANDEL = 5, LS_JULIA = 6, LS_COUNT = 7 };
+// LS_LEAF (one-visit-per-step mode only): the lane stands at a leaf primitive it has yet to test.
+enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS = 4, LS_MANDEL = 5, LS_JULIA = 6, LS_LEAF = 7, LS_COUNT = 8 };
 
 // Per-lane LDS slots (lane-interleaved: slot f of this lane at base[f * 64]).
 #define SC_PIXEL_FIELDS 8u   // mean xyz, M2 xyz, samples finished, path-bounce tally
@@ -110,6 +112,10 @@ PT_DEV bool trav_apply(const DScene& sc, Trav& tv, bool hit, float ht, uint32_t 
     return false;
 }
 
+// The state of a traversing lane whose current primitive is done: in one-visit-per-step mode a lane with more
+// primitives of its leaf to test waits for the next LEAF round, otherwise it walks on.
+PT_DEV uint32_t after_prim(const Trav& tv, bool single) { return single && tv.pi < tv.pend ? (uint32_t)LS_LEAF : (uint32_t)LS_WALK; }
+
 // Starts an estimator evaluation at the point of `ray` at distance t (+ `offset`, in the figure's unit space).
 PT_DEV void frac_start(const DPrim& g, const Ray& ray, float t, uint32_t phase, V3 offset, float* frac) {
     const float inv_radius = dm::rcp_(g.p[3]);
@@ -131,7 +137,7 @@ PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yx
 }
 // One step of a lane inside a fractal estimator: one iteration and, when the evaluation completes, what the
 // evaluation was for (march_step_fractal's logic around its two sdf calls, or finish_fractal's normal).
-PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park) {
+PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park, bool single) {
     PT_SITE(42);
     uint32_t* frac_u = (uint32_t*)frac;
     uint32_t* park_u = (uint32_t*)park;
@@ -195,14 +201,42 @@ PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t ma
     }
     if (trav_apply(sc, tv, r == MARCH_HIT, m.t, 0u)) return LS_POST;
     tv.pi += 1u;
-    return LS_WALK;
+    return after_prim(tv, single);
+}
+
+// One LEAF step: the lane tests the leaf primitive it stands at, or enters its marcher.  Returns the lane's next state.
+template <bool FRAC>
+PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, bool single, float* frac) {
+    const DPrim& g = sc.prims[tv.pi];
+    const uint32_t type = g.type;
+    bool hit = false;
+    float ht = 0.0f;
+    uint32_t sub = 0u;
+    if (type == FIG_TORUS) {
+        if (march_begin_torus(tv.ray, g, tv.m)) return LS_TORUS;
+    } else if (type == FIG_MEBIUS) {
+        if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
+    } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
+        if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) {
+            frac_start(g, tv.ray, tv.m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
+            return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
+        }
+    } else if (type != FIG_SKIP) {
+        hit = intersect_closed(tv.ray, tv.inv_dir, g, ht, sub);
+    }
+    if (trav_apply(sc, tv, hit, ht, sub)) return LS_POST;
+    tv.pi += 1u;
+    return after_prim(tv, single);
 }
 
 // One WALK step: walk inner nodes until the lane stands at a leaf primitive (same pops, pushes and guards as
 // trace_positive_walk / trace_shadow_walk), then test that primitive, or enter its marcher.  Returns the lane's
-// next state.  `single` (wave-uniform, for deep trees): a step is ONE node visit or ONE primitive test, so no lane
-// waits inside the step for the lane with the longest way down to a leaf (10 M triangles: +10 %; shallow trees
-// lose 1-5 % to the extra scheduling rounds).
+// next state.  `single` (wave-uniform, for deep trees): a step is ONE node visit, so no lane waits inside the step
+// for the lane with the longest way down to a leaf (10 M triangles: +10 %; shallow trees lose 1-5 % to the extra
+// scheduling rounds), and a lane that arrives at a leaf goes to LS_LEAF: node visits and primitive tests are
+// different code, and in one step a wave would run both for a few lanes each (measured on the 10 M-triangle
+// scene: 9.7 lanes per node-pair test, 2.6 per triangle test); served as states of their own, the primitive
+// tests run for the lanes that have gathered at leaves.
 template <bool FRAC>
 PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, bool single, float* frac) {
     bool walked = false;
@@ -245,32 +279,13 @@ PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint3
             }
         }
     }
-    if (single && walked) return LS_WALK;
-    const DPrim& g = sc.prims[tv.pi];
-    const uint32_t type = g.type;
-    bool hit = false;
-    float ht = 0.0f;
-    uint32_t sub = 0u;
-    if (type == FIG_TORUS) {
-        if (march_begin_torus(tv.ray, g, tv.m)) return LS_TORUS;
-    } else if (type == FIG_MEBIUS) {
-        if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
-    } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
-        if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) {
-            frac_start(g, tv.ray, tv.m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
-            return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
-        }
-    } else if (type != FIG_SKIP) {
-        hit = intersect_closed(tv.ray, tv.inv_dir, g, ht, sub);
-    }
-    if (trav_apply(sc, tv, hit, ht, sub)) return LS_POST;
-    tv.pi += 1u;
-    return LS_WALK;
+    if (single && walked) return LS_LEAF;
+    return leaf_step<FRAC>(sc, tv, march_steps, single, frac);
 }
 
 // One MARCH step of marcher `kind` (wave-uniform).
 template <bool FRAC>
-PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps) {
+PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, bool single) {
     const DPrim& g = sc.prims[tv.pi];
     int r;
     if (kind == LS_TORUS) { PT_SITE(40); r = march_step_torus(tv.ray, g, tv.m); }
@@ -279,7 +294,7 @@ PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t m
     if (r == MARCH_GO) return kind;
     if (trav_apply(sc, tv, r == MARCH_HIT, tv.m.t, 0u)) return LS_POST;
     tv.pi += 1u;
-    return LS_WALK;
+    return after_prim(tv, single);
 }
 
 // Pixel jobs.  A lane is not tied to one pixel: when its pixel has all its samples it writes the pixel back and

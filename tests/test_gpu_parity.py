@@ -358,6 +358,22 @@ def test_deep_bvh_heightfield_matches_oracle(pt):
     _compare(pt, sb, 128, 72, 3)
 
 
+@pytest.mark.parametrize("shares", ["12,2,4,4", "4,2,16,6", "64,2,4,1"])
+def test_deep_bvh_heightfield_in_single_visit_mode_matches_oracle(pt, shares, monkeypatch):
+    """What trees of millions of primitives run (one node visit per WALK step, lanes at leaf primitives as a state of their
+    own), forced on a tree the oracle finishes in seconds, with the shares of both deep scene classes and an extreme one."""
+    monkeypatch.setenv("PTX355_WALK_SINGLE", "1")
+    monkeypatch.setenv("PTX355_SHARES", shares)
+    sc = host.Scene.from_fixture(fixture("all"))
+    sc.append_heightfield(48, glass_every=16)
+    sc.build()
+    b = sc.buffers()
+    sb = hp.SceneBuffers(b["figs"], b["mats"], b["nodes"], b["prims"], b["lights"], b["infinite"], b["tex_pixels"], b["tex_infos"],
+                         hp.scene_from_fixture(fixture("all"))[1])
+    _compare(pt, sb, 128, 72, 3)
+    assert "sched" in pt.kernel_name()
+
+
 def test_error_reporting(pt):
     fresh = PathTracer(0)
     cam = hp.camera_to_gpu(hp.CameraConfig(), 8, 8)
@@ -392,26 +408,33 @@ def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w,
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
     cam = sc.camera(w, h)
     results = {}
-    # split: the scheduled fractal kernels' sample-granular jobs + fold ("2": in chunks of two samples)
-    for sched, tile, split in (("0", "1", "0"), ("1", "1", "0"), ("1", "1", "1"), ("1", "1", "2"), ("1", "64", "0"), ("0", "64", "0")):
+    # split: the scheduled fractal kernels' sample-granular jobs + fold ("2": in chunks of two samples); single: one node
+    # visit per WALK step with the lanes at leaf primitives served as a state of their own (what deep trees run),
+    # with leaf shares that serve them early ("64") and late ("2")
+    for sched, tile, split, single in (("0", "1", "0", ""), ("1", "1", "0", ""), ("1", "1", "1", ""), ("1", "1", "2", ""), ("1", "64", "0", ""),
+                                       ("0", "64", "0", ""), ("1", "1", "0", "64"), ("1", "64", "1", "2"), ("1", "64", "0", "5")):
         monkeypatch.setenv("PTX355_SCHED", sched)
         monkeypatch.setenv("PTX355_CLAIM_TILE", tile)
         monkeypatch.setenv("PTX355_SPLIT", "0" if split == "0" else "1")
         monkeypatch.setenv("PTX355_SPLIT_CHUNK", "2" if split == "2" else "1000")
+        if single:
+            monkeypatch.setenv("PTX355_WALK_SINGLE", "1")
+            monkeypatch.setenv("PTX355_SHARES", f"4,2,4,{single}")
+        else:
+            monkeypatch.delenv("PTX355_WALK_SINGLE", raising=False)
+            monkeypatch.delenv("PTX355_SHARES", raising=False)
         sc.upload_to(pt)  # the family is chosen at upload
         assert ("sched" in pt.kernel_name()) == (sched == "1")
         pt.enable_moments(True)
         pt.resize(w, h)
         pt.trace_n(cam, 0, 1, n)
         st = pt.stats()
-        results[(sched, tile, split)] = (pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
-                                  (st["paths"], st["bounces"], st["shadow_rays"]))
+        results[(sched, tile, split, single)] = (pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
+                                                 (st["paths"], st["bounces"], st["shadow_rays"]))
         pt.enable_moments(False)
-    monkeypatch.delenv("PTX355_SCHED")
-    monkeypatch.delenv("PTX355_CLAIM_TILE")
-    monkeypatch.delenv("PTX355_SPLIT")
-    monkeypatch.delenv("PTX355_SPLIT_CHUNK")
-    ref = results[("0", "1", "0")]
+    for k in ("PTX355_SCHED", "PTX355_CLAIM_TILE", "PTX355_SPLIT", "PTX355_SPLIT_CHUNK", "PTX355_WALK_SINGLE", "PTX355_SHARES"):
+        monkeypatch.delenv(k, raising=False)
+    ref = results[("0", "1", "0", "")]
     for key, r in results.items():
         assert same_bits(r[0], ref[0]) == 0 and same_bits(r[1], ref[1]) == 0, key
         assert (r[2] == ref[2]).all() and (r[3] == ref[3]).all() and r[4] == ref[4], key
