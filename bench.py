@@ -25,7 +25,7 @@ WORKLOADS = {
     # name: (fixture, width, height, default spp per step, label)
     "cornell": ("cornell_box", 1920, 1080, 128, "cornell_box.yaml 1920x1080 (configs[1]: analytic primitives, 1024 spp = 8 steps x 128)"),
     "teapot": ("teapot", 3840, 2160, 16, "teapot.yaml 3840x2160 OBJ BVH"),
-    "fractals": ("fractals", 1920, 1080, 32, "fractals.yaml 1920x1080 Mandelbulb/Julia ray-march"),
+    "fractals": ("fractals", 1920, 1080, 128, "fractals.yaml 1920x1080 Mandelbulb/Julia ray-march"),
     "all_mesh": ("all", 1920, 1080, 8, "all.yaml + synthetic height-field mesh 1920x1080"),
 }
 PEAK_FP32_VALU_TFLOPS = 157.3  # packed v_pk_fma_f32; 78.6 for one FMA per lane per clock

@@ -271,7 +271,7 @@ PT_DEV void sched_body(const TraceParams& P) {
             if (s >= (uint32_t)LS_TORUS && s <= (uint32_t)LS_JULIA && pop[s] > march_n) { march_n = pop[s]; march = s; }
         }
         if (live == 0u) break;
-        const bool single = P.walk_single != 0u;
+        const uint32_t single = P.walk_single;  // WALK mode
         uint32_t pick = fullest;
         if (pop[LS_LEAF] * P.share_leaf >= live) pick = LS_LEAF;
         else if (pop[LS_WALK] * P.share_walk >= live) pick = LS_WALK;
@@ -282,7 +282,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                 if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, single, frac);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
                 if (w == 0u || w * P.share_walk < live) break;
-                if (single && (uint32_t)__popcll(__ballot(S == LS_LEAF)) * P.share_leaf >= live) break;
+                if (single != 0u && (uint32_t)__popcll(__ballot(S == LS_LEAF)) * P.share_leaf >= live) break;
             }
         } else if (pick == LS_LEAF) {
             if (S == LS_LEAF) S = leaf_step<FRAC>(sc, tv, P.cam.fractal_march_steps, single, frac);
@@ -1050,18 +1050,18 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         P.claim_tile = c->claim_tile;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
-        if (const char* e = getenv("PTX355_WALK_SINGLE")) P.walk_single = e[0] != '0' ? 1u : 0u;  // measurement and test runs
+        if (const char* e = getenv("PTX355_WALK_SINGLE")) P.walk_single = (uint32_t)(e[0] - '0') <= 2u ? (uint32_t)(e[0] - '0') : 0u;  // measurement and test runs
         P.share_leaf = c->share_leaf;
     }
     // Fractal scenes: a pixel on a fractal's silhouette costs hundreds of times a background pixel, and with one
     // lane folding all n samples of its pixel the launch ends on a few lanes finishing theirs.  There the jobs
     // are single samples, staged and folded in order by ptx_fold_kernel, in chunks that bound the staging buffer
-    // (1 GiB) and the job count.  Radiance capture keeps whole-pixel jobs (its sample index is launch-relative).
+    // (4 GiB of the 288: 128 samples of a 1080p frame; the launch's fixed cost, its last waves draining, is paid per chunk) and the job count.  Radiance capture keeps whole-pixel jobs (its sample index is launch-relative).
     const bool split = c->sched && frac && c->split && n > 1u && !c->dbg;
     uint32_t chunk = n;
     if (split) {
         const size_t frame_pixels = (size_t)c->w * c->h;
-        size_t by_mem = ((size_t)1 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)P.n_blocks * 256u);
+        size_t by_mem = ((size_t)4 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)P.n_blocks * 256u);
         size_t m = by_mem < by_jobs ? by_mem : by_jobs;
         if (const char* e = getenv("PTX355_SPLIT_CHUNK")) { size_t v = (size_t)atoi(e); if (v >= 1 && v < m) m = v; }  // tests
         if (m < 1) m = 1;

@@ -38,7 +38,8 @@ struct TraceParams {
     uint32_t claim_tile;    // jobs a wave takes from job_counter at a time: 64, or 1 (lanes claim single pixels directly)
     uint32_t total_jobs;    // n_blocks * 256
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
-    uint32_t walk_single;   // scheduled kernels: one node visit per WALK step (deep trees)
+    uint32_t walk_single;   // scheduled kernels, WALK mode: 0 a step walks to a leaf primitive and tests it; 1 a step is one node visit and
+                            // lanes at leaf primitives wait in LS_LEAF (deep trees); 2 a step walks to a leaf primitive, tests wait in LS_LEAF
     uint32_t share_leaf;    // walk_single: lanes at a leaf primitive are served together from 1/share of the live lanes
     // Sample-granular jobs (scheduled fractal kernels, split_n > 0): job j is sample j % split_n of pixel job
     // j / split_n; a finished sample's radiance goes to staging[sample * frame_pixels + pixel] and the fold
@@ -114,7 +115,7 @@ PT_DEV bool trav_apply(const DScene& sc, Trav& tv, bool hit, float ht, uint32_t 
 
 // The state of a traversing lane whose current primitive is done: in one-visit-per-step mode a lane with more
 // primitives of its leaf to test waits for the next LEAF round, otherwise it walks on.
-PT_DEV uint32_t after_prim(const Trav& tv, bool single) { return single && tv.pi < tv.pend ? (uint32_t)LS_LEAF : (uint32_t)LS_WALK; }
+PT_DEV uint32_t after_prim(const Trav& tv, uint32_t mode) { return mode != 0u && tv.pi < tv.pend ? (uint32_t)LS_LEAF : (uint32_t)LS_WALK; }
 
 // Starts an estimator evaluation at the point of `ray` at distance t (+ `offset`, in the figure's unit space).
 PT_DEV void frac_start(const DPrim& g, const Ray& ray, float t, uint32_t phase, V3 offset, float* frac) {
@@ -137,7 +138,7 @@ PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yx
 }
 // One step of a lane inside a fractal estimator: one iteration and, when the evaluation completes, what the
 // evaluation was for (march_step_fractal's logic around its two sdf calls, or finish_fractal's normal).
-PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park, bool single) {
+PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park, uint32_t mode) {
     PT_SITE(42);
     uint32_t* frac_u = (uint32_t*)frac;
     uint32_t* park_u = (uint32_t*)park;
@@ -201,12 +202,12 @@ PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t ma
     }
     if (trav_apply(sc, tv, r == MARCH_HIT, m.t, 0u)) return LS_POST;
     tv.pi += 1u;
-    return after_prim(tv, single);
+    return after_prim(tv, mode);
 }
 
 // One LEAF step: the lane tests the leaf primitive it stands at, or enters its marcher.  Returns the lane's next state.
 template <bool FRAC>
-PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, bool single, float* frac) {
+PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint32_t mode, float* frac) {
     const DPrim& g = sc.prims[tv.pi];
     const uint32_t type = g.type;
     bool hit = false;
@@ -226,7 +227,7 @@ PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, bool
     }
     if (trav_apply(sc, tv, hit, ht, sub)) return LS_POST;
     tv.pi += 1u;
-    return after_prim(tv, single);
+    return after_prim(tv, mode);
 }
 
 // One WALK step: walk inner nodes until the lane stands at a leaf primitive (same pops, pushes and guards as
@@ -238,7 +239,8 @@ PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, bool
 // scene: 9.7 lanes per node-pair test, 2.6 per triangle test); served as states of their own, the primitive
 // tests run for the lanes that have gathered at leaves.
 template <bool FRAC>
-PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, bool single, float* frac) {
+PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, uint32_t mode, float* frac) {
+    const bool single = mode == 1u;
     bool walked = false;
     while (tv.pi >= tv.pend) {
         if (single && walked) return LS_WALK;
@@ -279,13 +281,13 @@ PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint3
             }
         }
     }
-    if (single && walked) return LS_LEAF;
-    return leaf_step<FRAC>(sc, tv, march_steps, single, frac);
+    if (mode != 0u && walked) return LS_LEAF;
+    return leaf_step<FRAC>(sc, tv, march_steps, mode, frac);
 }
 
 // One MARCH step of marcher `kind` (wave-uniform).
 template <bool FRAC>
-PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, bool single) {
+PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, uint32_t mode) {
     const DPrim& g = sc.prims[tv.pi];
     int r;
     if (kind == LS_TORUS) { PT_SITE(40); r = march_step_torus(tv.ray, g, tv.m); }
@@ -294,7 +296,7 @@ PT_DEV uint32_t march_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t m
     if (r == MARCH_GO) return kind;
     if (trav_apply(sc, tv, r == MARCH_HIT, tv.m.t, 0u)) return LS_POST;
     tv.pi += 1u;
-    return after_prim(tv, single);
+    return after_prim(tv, mode);
 }
 
 // Pixel jobs.  A lane is not tied to one pixel: when its pixel has all its samples it writes the pixel back and

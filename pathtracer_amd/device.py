@@ -116,11 +116,11 @@ class PathTracer:
         the arrays the reference's sequential builder gives."""
         aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
         n = len(aabbs)
-        nodes = np.zeros(max(1, 2 * n), dtype=NODE_DT)
-        prims = np.zeros(n, dtype=np.uint32)
+        nodes = np.empty(max(1, 2 * n), dtype=NODE_DT)
+        prims = np.empty(n, dtype=np.uint32)
         nn = C.c_uint32()
         self._ck(self.lib.ptx_bvh_build(self.h, _p(aabbs), n, _p(nodes), C.byref(nn), _p(prims)), "ptx_bvh_build")
-        return nodes[: nn.value].copy(), prims
+        return nodes[: nn.value], prims
 
     def debug_capture(self, max_samples: int):
         self._ck(self.lib.ptx_debug_capture(self.h, max_samples), "ptx_debug_capture")

@@ -234,13 +234,13 @@ def bvh_build(aabbs: np.ndarray):
     """Bvh::build (src/accel/bvh.rs:37-213) on the host over n boxes {min xyz, max xyz}: (nodes, primitive order)."""
     aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
     n = len(aabbs)
-    nodes = np.zeros(max(1, 2 * n), dtype=NODE_DT)
-    prims = np.zeros(n, dtype=np.uint32)
+    nodes = np.empty(max(1, 2 * n), dtype=NODE_DT)
+    prims = np.empty(n, dtype=np.uint32)
     nn = _U()
     rc = load().pth_bvh_build(None, aabbs.ctypes.data_as(_P), n, nodes.ctypes.data_as(_P), C.byref(nn), prims.ctypes.data_as(_P))
     if rc != 0:
         raise RuntimeError(f"pth_bvh_build failed ({rc})")
-    return nodes[: nn.value].copy(), prims
+    return nodes[: nn.value], prims
 
 
 class Accumulator:
