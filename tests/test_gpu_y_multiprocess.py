@@ -91,3 +91,53 @@ def test_two_ranks_sample_split_and_tiles():
     pt.trace_n(cam, 0, 1, 3)
     assert same_bits(tiles, pt.read_accum()) == 0 and (tiles_out == pt.read_output()).all()
     pt.close()
+
+
+def _rccl_worker(port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import host, multigpu
+    from pathtracer_amd.device import PathTracer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    device = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h = 96, 54
+    cam = sc.camera(w, h)
+    pt = PathTracer(0)
+    sc.upload_to(pt)
+    pt.enable_moments(True)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, 6)
+    before, before_m2, before_out = pt.read_accum(), pt.read_moments(), pt.read_output()
+    n = multigpu.merge_sample_split(pt, dist, device, [6], cam)   # all-to-all, all-gather, tonemap on the device buffers
+    after, after_m2, after_out = pt.read_accum(), pt.read_moments(), pt.read_output()
+    multigpu.assemble_tiles(pt, dist, device, cam)               # all-reduce on the aliased accumulation buffer
+    tiles = pt.read_accum()
+    q.put((n, before, before_m2, before_out, after, after_m2, after_out, tiles))
+    pt.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_on_aliased_device_buffers_single_rank():
+    """The calls `bench.py --gpus N` makes over RCCL (all-to-all, all-gather and all-reduce on tensors that alias the
+    context's device buffers), with the one rank a one-GPU box allows: a world of one must leave the frame as it was."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        n, before, before_m2, before_out, after, after_m2, after_out, tiles = q.get(timeout=150)
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    finally:
+        if p.is_alive():
+            p.kill()
+    assert n == 6
+    assert same_bits(before, after) == 0 and same_bits(before_m2, after_m2) == 0 and (before_out == after_out).all()
+    assert same_bits(before, tiles) == 0
