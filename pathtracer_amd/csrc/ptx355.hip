@@ -21,6 +21,7 @@
 #include "sched_dev.h"
 #include "post_dev.h"
 #include "bvh_build.h"
+#include "relayout.h"
 
 #define PTX_BLOCK 256
 #define PT_DEEP_TREE 20u  // stack entries from which a tree counts as deep (millions of primitives): one node visit per WALK step
@@ -605,74 +606,6 @@ int upload_vec(ptx_ctx* c, const std::vector<T>& v, const T** dst) {
     return PTX_OK;
 }
 
-// Re-layout of one reference figure (src/scene/shape.rs:223-248) into the 64-byte intersector record.
-// The division contract's reciprocal (dmath_dev.h) for values precomputed on the host.
-float host_rcp(float y) {
-    if (y != y) return y;
-    uint32_t b;
-    memcpy(&b, &y, 4);
-    const uint32_t sign = b & 0x80000000u, inf = sign | 0x7f800000u;
-    float r;
-    if ((b & 0x7f800000u) == 0u) { memcpy(&r, &inf, 4); return r; }
-    volatile float q = 1.0f / y;
-    r = q;
-    memcpy(&b, &r, 4);
-    if ((b & 0x7f800000u) == 0u) memcpy(&r, &sign, 4);
-    return r;
-}
-
-// IEEE maxNum with +0 above -0, as v_max_f32 and the oracle's fmax_.
-float host_fmax(float a, float b) {
-    if (a != a) return b;
-    if (b != b) return a;
-    if (a == b) { uint32_t u; memcpy(&u, &a, 4); return (u & 0x80000000u) ? b : a; }
-    return a > b ? a : b;
-}
-
-DPrim make_prim(const ptx_shape& f, uint32_t fig) {
-    DPrim g;
-    memset(&g, 0, sizeof(g));
-    g.type = f.csg_op == 1u ? (uint32_t)FIG_SKIP : f.shape_type;
-    g.fig = fig;
-    float* p = g.p;
-    p[0] = f.position[0]; p[1] = f.position[1]; p[2] = f.position[2];
-    auto put3 = [&](int at, const float* v) { p[at] = v[0]; p[at + 1] = v[1]; p[at + 2] = v[2]; };
-    // Ray-independent subexpressions are evaluated here once, with the single f32 operations (volatile: no
-    // contraction, no reassociation) the intersectors would otherwise repeat per ray.
-    volatile float a, b;
-    switch (f.shape_type) {
-        case FIG_SPHERE: p[3] = f.radius; a = f.radius * f.radius; p[4] = a; break;
-        case FIG_CUBE:
-            p[3] = f.radius;
-            for (int i = 0; i < 3; i++) { a = f.position[i] - f.radius; b = f.position[i] + f.radius; p[4 + i] = a; p[7 + i] = b; }
-            break;
-        case FIG_TETRAHEDRON: case FIG_SKYBOX: p[3] = f.radius; break;
-        case FIG_MEBIUS: p[3] = f.radius; a = f.radius * 1.5f; a = a * a; p[4] = a; break;
-        case FIG_PLANE: put3(3, f.normal); break;
-        case FIG_DISC: put3(3, f.normal); p[6] = f.radius; a = f.radius * f.radius; p[7] = a; break;
-        case FIG_CYLINDER: put3(3, f.normal); p[6] = f.radius; p[7] = f.height; break;
-        case FIG_CONE: put3(3, f.normal); p[6] = f.radius; p[7] = f.height; p[8] = f.radius2; break;
-        case FIG_TORUS: p[3] = f.radius; p[4] = f.radius2; a = f.radius + f.radius2; a = a + f.radius2; a = a * a; p[5] = a; break;
-        case FIG_TRIANGLE: {
-            // e1 = v1 - v0, e2 = v2 - v0: the same single f32 subtractions triangle.wgsl:9-10 performs per ray.
-            volatile float e[6];
-            for (int i = 0; i < 3; i++) { e[i] = f.v1[i] - f.v0[i]; e[3 + i] = f.v2[i] - f.v0[i]; }
-            put3(0, f.v0);
-            for (int i = 0; i < 6; i++) p[3 + i] = e[i];
-            break;
-        }
-        case FIG_MANDELBULB: p[3] = f.radius; p[4] = f.v0[0]; p[5] = f.v0[1]; a = f.radius * 1.5f; a = a * a; p[9] = a; break;
-        case FIG_JULIA: p[3] = f.radius; p[4] = f.v0[1]; put3(5, f.rotation); p[8] = f.radius2; a = f.radius * 1.5f; a = a * a; p[9] = a; break;
-        case FIG_ELLIPSOID:
-            p[3] = f.radius; p[4] = f.height; p[5] = f.radius2;
-            p[6] = host_rcp(f.radius); p[7] = host_rcp(host_fmax(f.height, f.radius)); p[8] = host_rcp(host_fmax(f.radius2, f.radius));
-            break;
-        case FIG_PARABOLOID: case FIG_HYPERBOLOID: case FIG_PYRAMID: p[3] = f.radius; p[4] = f.height; break;
-        default: g.type = FIG_SKIP; break;  // unknown type: dispatch.wgsl:78-81 reports no hit
-    }
-    return g;
-}
-
 int collect_timing(ptx_ctx* c) {
     for (auto& pr : c->pending) {
         float ms = 0.0f;
@@ -692,6 +625,115 @@ int get_event(ptx_ctx* c, hipEvent_t* e) {
     return PTX_OK;
 }
 
+struct DevBufs {  // device allocations of one build, released on every exit path
+    std::vector<void*> ptrs;
+    ~DevBufs() { release(); }
+    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+    hipError_t alloc(void** out, size_t bytes) {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+};
+int scan_u32(ptx_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* sums) {
+    const uint32_t nblocks = (n + bvhb::SCAN_TILE - 1u) / bvhb::SCAN_TILE;
+    hipLaunchKernelGGL(bvhb::scan_sums_kernel, dim3(nblocks), dim3(256), 0, c->stream, in, n, sums);
+    hipLaunchKernelGGL(bvhb::scan_top_kernel, dim3(1), dim3(256), 0, c->stream, sums, nblocks, out + n);
+    hipLaunchKernelGGL(bvhb::scan_final_kernel, dim3(nblocks), dim3(256), 0, c->stream, in, n, (const uint32_t*)sums, out);
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+
+// The re-layout on the device (relayout.h): the raw arrays are copied over, one lane per record builds the shading,
+// primitive and node-pair records and makes ptx_upload_scene's checks; what is small (lights, planes, subtraction
+// shapes, textures) stays with the caller.  Leaves sc.prims / sc.shade / sc.pairs set and owned by the scene.
+int relayout_on_device(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx_material* mats, uint32_t nmat,
+                       const ptx_bvh_node* nodes, uint32_t nnode, const uint32_t* prims, uint32_t nprim, bool have_tree,
+                       DScene& sc, uint32_t& npair, uint32_t& depth, uint32_t& type_mask, uint32_t& root_ref,
+                       uint32_t& neg_count, uint32_t& sky_index) {
+    using namespace relay;
+    DevBufs tmp;  // the raw copies and the scratch: released when the records are built
+    ptx_shape* d_figs;
+    ptx_material* d_mats;
+    ptx_bvh_node* d_nodes;
+    uint32_t *d_prims, *d_res, *d_inner, *d_pair_of, *d_sums, *d_depth;
+    hipStream_t st = c->stream;
+    HIP_TRY(c, tmp.alloc((void**)&d_figs, (size_t)nfig * sizeof(ptx_shape)));
+    HIP_TRY(c, tmp.alloc((void**)&d_mats, (size_t)nmat * sizeof(ptx_material)));
+    HIP_TRY(c, tmp.alloc((void**)&d_nodes, (size_t)nnode * sizeof(ptx_bvh_node)));
+    HIP_TRY(c, tmp.alloc((void**)&d_prims, (size_t)nprim * 4));
+    HIP_TRY(c, tmp.alloc((void**)&d_res, R_WORDS * 4));
+    HIP_TRY(c, tmp.alloc((void**)&d_inner, (size_t)nnode * 4));
+    HIP_TRY(c, tmp.alloc((void**)&d_pair_of, ((size_t)nnode + 1) * 4));
+    HIP_TRY(c, tmp.alloc((void**)&d_sums, ((size_t)nnode / bvhb::SCAN_TILE + 2) * 4));
+    HIP_TRY(c, tmp.alloc((void**)&d_depth, (size_t)nnode * 4));
+    auto scene_alloc = [&](void** out, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        if (e == hipSuccess) c->scene_allocs.push_back(*out);
+        return e;
+    };
+    DShade* d_shade;
+    DPrim* d_dprims;
+    HIP_TRY(c, scene_alloc((void**)&d_shade, (size_t)nfig * sizeof(DShade)));
+    HIP_TRY(c, scene_alloc((void**)&d_dprims, (size_t)nprim * sizeof(DPrim)));
+    if (nfig) HIP_TRY(c, hipMemcpyAsync(d_figs, figs, (size_t)nfig * sizeof(ptx_shape), hipMemcpyHostToDevice, st));
+    if (nmat) HIP_TRY(c, hipMemcpyAsync(d_mats, mats, (size_t)nmat * sizeof(ptx_material), hipMemcpyHostToDevice, st));
+    if (nnode) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nnode * sizeof(ptx_bvh_node), hipMemcpyHostToDevice, st));
+    if (nprim) HIP_TRY(c, hipMemcpyAsync(d_prims, prims, (size_t)nprim * 4, hipMemcpyHostToDevice, st));
+    const uint32_t res0[R_WORDS] = {0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    HIP_TRY(c, hipMemcpyAsync(d_res, res0, sizeof(res0), hipMemcpyHostToDevice, st));
+    auto blocks = [](uint32_t n) { return dim3((n + 255u) / 256u); };
+    if (nfig) hipLaunchKernelGGL(shade_kernel, blocks(nfig), dim3(256), 0, st, (const ptx_shape*)d_figs, nfig, (const ptx_material*)d_mats, nmat, d_shade, d_res);
+    if (nprim) hipLaunchKernelGGL(prim_kernel, blocks(nprim), dim3(256), 0, st, (const ptx_shape*)d_figs, nfig, (const uint32_t*)d_prims, nprim, d_dprims, d_res);
+    if (have_tree) hipLaunchKernelGGL(node_kernel, blocks(nnode), dim3(256), 0, st, (const ptx_bvh_node*)d_nodes, nnode, nprim, d_inner, d_res);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t res[R_WORDS];
+    HIP_TRY(c, hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    // the first failing check in the order the host loops make them
+    if (res[R_ERRORS] & E_MATERIAL) return fail(c, PTX_ERR_BAD_ARG, "figure material_idx out of range");
+    if (res[R_ERRORS] & E_PRIM) return fail(c, PTX_ERR_BAD_ARG, "bvh_prims entry out of range");
+    if (res[R_ERRORS] & E_CHILD) return fail(c, PTX_ERR_BAD_ARG, "inner BVH node with child index out of order or range");
+    if (res[R_ERRORS] & E_LEAF_BIG) return fail(c, PTX_ERR_UNSUPPORTED, "BVH leaf with more than 7 primitives");
+    if (res[R_ERRORS] & E_LEAF_RANGE) return fail(c, PTX_ERR_BAD_ARG, "BVH leaf range outside bvh_prims");
+    neg_count = res[R_NEG_COUNT];
+    sky_index = res[R_SKY_INDEX];
+    type_mask = res[R_TYPE_MASK];
+    npair = 0u;
+    depth = 0u;
+    root_ref = 0u;
+    DNodePair* d_pairs = nullptr;
+    if (have_tree) {
+        { int rc = scan_u32(c, d_inner, nnode, d_pair_of, d_sums); if (rc) return rc; }
+        HIP_TRY(c, hipMemcpyAsync(&npair, d_pair_of + nnode, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        HIP_TRY(c, scene_alloc((void**)&d_pairs, (size_t)npair * sizeof(DNodePair)));
+        hipLaunchKernelGGL(pair_kernel, blocks(nnode), dim3(256), 0, st, (const ptx_bvh_node*)d_nodes, nnode, (const uint32_t*)d_pair_of, d_pairs);
+        hipLaunchKernelGGL(depth_init_kernel, blocks(nnode), dim3(256), 0, st, d_depth, nnode);
+        HIP_TRY(c, hipGetLastError());
+        root_ref = nodes[0].prim_count > 0u ? (nodes[0].left_or_prim | (nodes[0].prim_count << PT_REF_BITS)) : 0u;  // the root's pair is record 0
+        // Longest chain of inner nodes from the root (bounds the stack occupancy): one level per pass.
+        if (nodes[0].prim_count == 0u)
+            for (uint32_t level = 0u;; level++) {
+                depth = level + 1u;
+                uint32_t changed = 0u;
+                HIP_TRY(c, hipMemsetAsync(d_res + R_CHANGED, 0, 4, st));
+                hipLaunchKernelGGL(depth_pass_kernel, blocks(nnode), dim3(256), 0, st, (const ptx_bvh_node*)d_nodes, nnode, d_depth, level, d_res);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipMemcpyAsync(&changed, d_res + R_CHANGED, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+                if (!changed) break;
+                if (level > nnode) return fail(c, PTX_ERR_STATE, "BVH depth pass does not end");
+            }
+    } else {
+        HIP_TRY(c, scene_alloc((void**)&d_pairs, 0));
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    sc.prims = d_dprims;
+    sc.shade = d_shade;
+    sc.pairs = d_pairs;
+    return PTX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -737,13 +779,13 @@ const char* ptx_last_error(const ptx_ctx* c) { return c ? c->err.c_str() : "null
 // steps: trees read from global memory (meshes) and the long ray marchers (Moebius, Mandelbulb, Julia); small
 // closed-form scenes (the Cornell box, torus included) run faster in lockstep.  PTX355_SCHED=0/1 in the
 // environment overrides the rule (measurement runs).
-static bool pick_sched(const DScene& sc, const std::vector<DPrim>& prims) {
+// type_mask: 1 << type over the BVH primitives that can be hit.
+static bool pick_sched(const DScene& sc, uint32_t type_mask) {
     if (const char* e = getenv("PTX355_SCHED")) return e[0] == '1';
     if (sc.lds_scene_bytes == 0u || sc.has_fractals != 0u) return true;
-    for (const DPrim& g : prims)
-        if (g.type == FIG_MEBIUS) return true;
-    return false;
+    return (type_mask & (1u << FIG_MEBIUS)) != 0u;
 }
+
 
 int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx_material* mats, uint32_t nmat,
                      const ptx_bvh_node* nodes, uint32_t nnode, const uint32_t* prims, uint32_t nprim,
@@ -757,42 +799,122 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     if (nprim > PT_REF_MASK || nnode > PT_REF_MASK) return fail(c, PTX_ERR_UNSUPPORTED, "more than 2^29 nodes or primitives");
-    for (uint32_t i = 0; i < nfig; i++)
-        if (figs[i].material_idx >= nmat) return fail(c, PTX_ERR_BAD_ARG, "figure material_idx out of range");
+    // Where the re-layout runs: large scenes on the device (relayout.h), small ones on the host, whose loops cost
+    // less than the launches.  Both give the same records.  PTX355_UPLOAD=host|device overrides (tests, measurements).
+    bool on_device = nfig >= 65536u || nprim >= 65536u;
+    if (const char* e = getenv("PTX355_UPLOAD")) on_device = e[0] == 'd';
 
-    std::vector<DShade> shade(nfig);
     std::vector<DNeg> negs;
     int32_t sky_tex = -1;
     float sky_color[3] = {0, 0, 0};
-    for (uint32_t i = 0; i < nfig; i++) {
-        const ptx_shape& f = figs[i];
-        const ptx_material& m = mats[f.material_idx];
-        shade[i].mat = m;
-        shade[i].texture_scale = f.texture_scale;
-        shade[i].uv0 = f._pad2; shade[i].uv1 = f._pad3; shade[i].uv2 = f._pad4;
-        if (f.csg_op == 1u) {
-            DNeg n;
-            memset(&n, 0, sizeof(n));
-            n.type = f.shape_type; n.radius = f.radius; n.radius2 = f.radius2; n.height = f.height;
-            memcpy(n.pos, f.position, 12);
-            memcpy(n.normal, f.normal, 12);
-            negs.push_back(n);
+    auto add_neg = [&](const ptx_shape& f) {
+        DNeg n;
+        memset(&n, 0, sizeof(n));
+        n.type = f.shape_type; n.radius = f.radius; n.radius2 = f.radius2; n.height = f.height;
+        memcpy(n.pos, f.position, 12);
+        memcpy(n.normal, f.normal, 12);
+        negs.push_back(n);
+    };
+    DScene sc;
+    memset(&sc, 0, sizeof(sc));
+    int rc;
+    uint32_t root_ref = 0, depth = 0, eff_nprim = 0, npair = 0, type_mask = 0;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    const bool have_tree = nnode > 0 && nprim > 0;
+    if (!on_device) {
+        for (uint32_t i = 0; i < nfig; i++)
+            if (figs[i].material_idx >= nmat) return fail(c, PTX_ERR_BAD_ARG, "figure material_idx out of range");
+        std::vector<DShade> shade(nfig);
+        for (uint32_t i = 0; i < nfig; i++) {
+            const ptx_shape& f = figs[i];
+            const ptx_material& m = mats[f.material_idx];
+            shade[i].mat = m;
+            shade[i].texture_scale = f.texture_scale;
+            shade[i].uv0 = f._pad2; shade[i].uv1 = f._pad3; shade[i].uv2 = f._pad4;
+            if (f.csg_op == 1u) add_neg(f);
+            if (sky_tex < 0 && f.shape_type == FIG_SKYBOX && m.texture_id >= 0) {
+                sky_tex = m.texture_id;
+                memcpy(sky_color, m.base_color, 12);
+            }
         }
-        if (sky_tex < 0 && f.shape_type == FIG_SKYBOX && m.texture_id >= 0) {
+        std::vector<DPrim> dprims(nprim);
+        for (uint32_t s = 0; s < nprim; s++) {
+            if (prims[s] >= nfig) return fail(c, PTX_ERR_BAD_ARG, "bvh_prims entry out of range");
+            dprims[s] = make_prim(figs[prims[s]], prims[s]);
+            if (dprims[s].type < 32u) type_mask |= 1u << dprims[s].type;
+        }
+        // Node pairs.  Children must have larger indices than their parent (true of the reference's
+        // pre-order flatten, bvh.rs:188-213), which also rules out cycles.
+        std::vector<DNodePair> pairs;
+        if (have_tree) {
+            std::vector<uint32_t> pair_of(nnode, 0xFFFFFFFFu);
+            uint32_t np = 0;
+            for (uint32_t i = 0; i < nnode; i++) {
+                const ptx_bvh_node& nd = nodes[i];
+                if (nd.prim_count == 0u) {
+                    if (i + 1 >= nnode || nd.left_or_prim >= nnode || nd.left_or_prim <= i)
+                        return fail(c, PTX_ERR_BAD_ARG, "inner BVH node with child index out of order or range");
+                    pair_of[i] = np++;
+                } else {
+                    if (nd.prim_count > 7u) return fail(c, PTX_ERR_UNSUPPORTED, "BVH leaf with more than 7 primitives");
+                    if ((uint64_t)nd.left_or_prim + nd.prim_count > nprim) return fail(c, PTX_ERR_BAD_ARG, "BVH leaf range outside bvh_prims");
+                }
+            }
+            pairs.resize(np);
+            auto child = [&](uint32_t ci, float* mn, float* mx, uint32_t* ref, uint32_t* cnt) {
+                const ptx_bvh_node& ch = nodes[ci];
+                memcpy(mn, ch.aabb_min, 12);
+                memcpy(mx, ch.aabb_max, 12);
+                if (ch.prim_count > 0u) { *ref = ch.left_or_prim; *cnt = ch.prim_count; }
+                else { *ref = pair_of[ci]; *cnt = 0u; }
+            };
+            for (uint32_t i = 0; i < nnode; i++) {
+                if (nodes[i].prim_count != 0u) continue;
+                DNodePair& pr = pairs[pair_of[i]];
+                child(i + 1, pr.lmin, pr.lmax, &pr.lref, &pr.lcnt);
+                child(nodes[i].left_or_prim, pr.rmin, pr.rmax, &pr.rref, &pr.rcnt);
+            }
+            root_ref = nodes[0].prim_count > 0u ? (nodes[0].left_or_prim | (nodes[0].prim_count << PT_REF_BITS)) : pair_of[0];
+            // Longest chain of inner nodes from the root: bounds the stack occupancy.
+            std::vector<std::pair<uint32_t, uint32_t>> todo;
+            todo.push_back({0u, 0u});
+            while (!todo.empty()) {
+                auto [ni, d] = todo.back();
+                todo.pop_back();
+                if (nodes[ni].prim_count != 0u) continue;
+                depth = d + 1 > depth ? d + 1 : depth;
+                todo.push_back({ni + 1, d + 1});
+                todo.push_back({nodes[ni].left_or_prim, d + 1});
+            }
+        }
+        npair = (uint32_t)pairs.size();
+        if ((rc = upload_vec(c, dprims, &sc.prims)) || (rc = upload_vec(c, shade, &sc.shade)) || (rc = upload_vec(c, pairs, &sc.pairs))) {
+            free_scene(c);
+            return rc;
+        }
+    } else {
+        uint32_t neg_count = 0u, sky_index = 0xFFFFFFFFu;
+        rc = relayout_on_device(c, figs, nfig, mats, nmat, nodes, nnode, prims, nprim, have_tree, sc, npair, depth, type_mask, root_ref, neg_count, sky_index);
+        if (rc) { free_scene(c); return rc; }
+        if (neg_count > 0u)  // rare: list the subtraction shapes in figure order
+            for (uint32_t i = 0; i < nfig; i++)
+                if (figs[i].csg_op == 1u) add_neg(figs[i]);
+        if (sky_index != 0xFFFFFFFFu) {
+            const ptx_material& m = mats[figs[sky_index].material_idx];
             sky_tex = m.texture_id;
             memcpy(sky_color, m.base_color, 12);
         }
     }
-    std::vector<DPrim> dprims(nprim);
-    for (uint32_t s = 0; s < nprim; s++) {
-        if (prims[s] >= nfig) return fail(c, PTX_ERR_BAD_ARG, "bvh_prims entry out of range");
-        dprims[s] = make_prim(figs[prims[s]], prims[s]);
+    if (have_tree) {
+        memcpy(root_min, nodes[0].aabb_min, 12);
+        memcpy(root_max, nodes[0].aabb_max, 12);
+        eff_nprim = nprim;
     }
     std::vector<DPrim> dinf;
     for (uint32_t i = 0; i < ninf; i++) {
         uint32_t fi = infinite[i];
         if (fi == 0xFFFFFFFFu) continue;  // the reference's empty-list placeholder (bvh.wgsl:196-199)
-        if (fi >= nfig) return fail(c, PTX_ERR_BAD_ARG, "infinite_indices entry out of range");
+        if (fi >= nfig) { free_scene(c); return fail(c, PTX_ERR_BAD_ARG, "infinite_indices entry out of range"); }
         if (figs[fi].csg_op == 1u) continue;  // bvh.wgsl:200-203
         dinf.push_back(make_prim(figs[fi], fi));
     }
@@ -800,7 +922,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     for (uint32_t i = 0; i < nlight; i++) {
         uint32_t fi = lights[i];
         if (fi == 0xFFFFFFFFu && nlight == 1u) break;  // placeholder list
-        if (fi >= nfig) return fail(c, PTX_ERR_BAD_ARG, "light_indices entry out of range");
+        if (fi >= nfig) { free_scene(c); return fail(c, PTX_ERR_BAD_ARG, "light_indices entry out of range"); }
         const ptx_shape& f = figs[fi];
         const ptx_material& m = mats[f.material_idx];
         DLight L;
@@ -812,67 +934,11 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
         volatile float a = 4.0f * PT_PI;  // lighting.wgsl:24: 4.0 * PI * r * r, left to right
         a = a * f.radius;
         a = a * f.radius;
-        volatile float pdf = host_rcp(a);
+        volatile float pdf = pt_host_rcp(a);
         L.area_pdf = pdf;
         dl.push_back(L);
     }
-
-    // Node pairs.  Children must have larger indices than their parent (true of the reference's
-    // pre-order flatten, bvh.rs:188-213), which also rules out cycles.
-    std::vector<DNodePair> pairs;
-    uint32_t root_ref = 0, depth = 0, eff_nprim = 0;
-    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
-    if (nnode > 0 && nprim > 0) {
-        std::vector<uint32_t> pair_of(nnode, 0xFFFFFFFFu);
-        uint32_t np = 0;
-        for (uint32_t i = 0; i < nnode; i++) {
-            const ptx_bvh_node& nd = nodes[i];
-            if (nd.prim_count == 0u) {
-                if (i + 1 >= nnode || nd.left_or_prim >= nnode || nd.left_or_prim <= i)
-                    return fail(c, PTX_ERR_BAD_ARG, "inner BVH node with child index out of order or range");
-                pair_of[i] = np++;
-            } else {
-                if (nd.prim_count > 7u) return fail(c, PTX_ERR_UNSUPPORTED, "BVH leaf with more than 7 primitives");
-                if ((uint64_t)nd.left_or_prim + nd.prim_count > nprim) return fail(c, PTX_ERR_BAD_ARG, "BVH leaf range outside bvh_prims");
-            }
-        }
-        pairs.resize(np);
-        auto child = [&](uint32_t ci, float* mn, float* mx, uint32_t* ref, uint32_t* cnt) {
-            const ptx_bvh_node& ch = nodes[ci];
-            memcpy(mn, ch.aabb_min, 12);
-            memcpy(mx, ch.aabb_max, 12);
-            if (ch.prim_count > 0u) { *ref = ch.left_or_prim; *cnt = ch.prim_count; }
-            else { *ref = pair_of[ci]; *cnt = 0u; }
-        };
-        for (uint32_t i = 0; i < nnode; i++) {
-            if (nodes[i].prim_count != 0u) continue;
-            DNodePair& pr = pairs[pair_of[i]];
-            child(i + 1, pr.lmin, pr.lmax, &pr.lref, &pr.lcnt);
-            child(nodes[i].left_or_prim, pr.rmin, pr.rmax, &pr.rref, &pr.rcnt);
-        }
-        const ptx_bvh_node& root = nodes[0];
-        memcpy(root_min, root.aabb_min, 12);
-        memcpy(root_max, root.aabb_max, 12);
-        root_ref = root.prim_count > 0u ? (root.left_or_prim | (root.prim_count << PT_REF_BITS)) : pair_of[0];
-        // Longest chain of inner nodes from the root: bounds the stack occupancy.
-        std::vector<std::pair<uint32_t, uint32_t>> todo;
-        todo.push_back({0u, 0u});
-        while (!todo.empty()) {
-            auto [ni, d] = todo.back();
-            todo.pop_back();
-            if (nodes[ni].prim_count != 0u) continue;
-            depth = d + 1 > depth ? d + 1 : depth;
-            todo.push_back({ni + 1, d + 1});
-            todo.push_back({nodes[ni].left_or_prim, d + 1});
-        }
-        eff_nprim = nprim;
-    }
-
-    DScene sc;
-    memset(&sc, 0, sizeof(sc));
-    int rc;
-    if ((rc = upload_vec(c, dprims, &sc.prims)) || (rc = upload_vec(c, dinf, &sc.inf)) || (rc = upload_vec(c, shade, &sc.shade)) ||
-        (rc = upload_vec(c, pairs, &sc.pairs)) || (rc = upload_vec(c, dl, &sc.lights)) || (rc = upload_vec(c, negs, &sc.negs))) {
+    if ((rc = upload_vec(c, dinf, &sc.inf)) || (rc = upload_vec(c, dl, &sc.lights)) || (rc = upload_vec(c, negs, &sc.negs))) {
         free_scene(c);
         return rc;
     }
@@ -902,25 +968,23 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     uint32_t entries = depth + 1;
     sc.stack_entries = entries > 31u ? 31u : entries;
     sc.lds_stack_entries = sc.stack_entries;  // reduced below for the global-memory kernels
-    sc.npair = (uint32_t)pairs.size();
-    sc.has_fractals = 0u;
-    for (const DPrim& g : dprims)
-        if (g.type == FIG_MANDELBULB || g.type == FIG_JULIA) sc.has_fractals = 1u;
+    sc.npair = npair;
+    const uint32_t fractal_bits = (1u << FIG_MANDELBULB) | (1u << FIG_JULIA);
+    sc.has_fractals = (type_mask & fractal_bits) != 0u ? 1u : 0u;
     {
-        size_t bytes = dprims.size() * sizeof(DPrim) + dinf.size() * sizeof(DPrim) + pairs.size() * sizeof(DNodePair) +
-                       shade.size() * sizeof(DShade) + dl.size() * sizeof(DLight) + negs.size() * sizeof(DNeg);
+        size_t bytes = (size_t)nprim * sizeof(DPrim) + dinf.size() * sizeof(DPrim) + (size_t)npair * sizeof(DNodePair) +
+                       (size_t)nfig * sizeof(DShade) + dl.size() * sizeof(DLight) + negs.size() * sizeof(DNeg);
         sc.lds_scene_bytes = bytes <= PT_LDS_SCENE_MAX ? (uint32_t)bytes : 0u;
         if (sc.lds_scene_bytes == 0u && sc.lds_stack_entries > PT_LDS_STACK) sc.lds_stack_entries = PT_LDS_STACK;
     }
     c->sc = sc;
     c->have_scene = true;
-    c->sched = pick_sched(sc, dprims);
+    c->sched = pick_sched(sc, type_mask);
     {
         const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {4u, 2u, 4u};
         // deep trees (one node visit per step, lanes at leaf primitives served as a state of their own): walk, post, march, leaf
         const uint32_t deep_mesh[4] = {12u, 2u, 4u, 4u}, deep_mixed[4] = {4u, 2u, 16u, 6u};
-        bool marchers = false;
-        for (const DPrim& g : dprims) marchers = marchers || g.type == FIG_TORUS || g.type == FIG_MEBIUS || g.type == FIG_MANDELBULB || g.type == FIG_JULIA;
+        const bool marchers = (type_mask & ((1u << FIG_TORUS) | (1u << FIG_MEBIUS) | fractal_bits)) != 0u;
         const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
         c->share_leaf = 4u;
         if (sc.stack_entries >= PT_DEEP_TREE) {
@@ -1207,26 +1271,6 @@ extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
 #endif
 
 // ---- GPU BVH build (bvh_build.h) ---------------------------------------------------------------------------------------
-namespace {
-struct DevBufs {  // device allocations of one build, released on every exit path
-    std::vector<void*> ptrs;
-    ~DevBufs() { release(); }
-    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
-    hipError_t alloc(void** out, size_t bytes) {
-        hipError_t e = hipMalloc(out, bytes ? bytes : 4);
-        if (e == hipSuccess) ptrs.push_back(*out);
-        return e;
-    }
-};
-int scan_u32(ptx_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* sums) {
-    const uint32_t nblocks = (n + bvhb::SCAN_TILE - 1u) / bvhb::SCAN_TILE;
-    hipLaunchKernelGGL(bvhb::scan_sums_kernel, dim3(nblocks), dim3(256), 0, c->stream, in, n, sums);
-    hipLaunchKernelGGL(bvhb::scan_top_kernel, dim3(1), dim3(256), 0, c->stream, sums, nblocks, out + n);
-    hipLaunchKernelGGL(bvhb::scan_final_kernel, dim3(nblocks), dim3(256), 0, c->stream, in, n, (const uint32_t*)sums, out);
-    HIP_TRY(c, hipGetLastError());
-    return PTX_OK;
-}
-}  // namespace
 
 int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* prim_indices_out) {
     if (!c || !nodes_out || !n_nodes_out || (n > 0u && (!aabbs || !prim_indices_out))) return PTX_ERR_BAD_ARG;

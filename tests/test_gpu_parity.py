@@ -374,6 +374,62 @@ def test_deep_bvh_heightfield_in_single_visit_mode_matches_oracle(pt, shares, mo
     assert "sched" in pt.kernel_name()
 
 
+@pytest.mark.parametrize("name,quads", [("cornell_box", 0), ("teapot", 0), ("fractals", 0), ("all", 0), ("planet", 0), ("all", 40)])
+def test_scene_relayout_on_the_device_equals_the_host_relayout(pt, name, quads, monkeypatch):
+    """ptx_upload_scene builds the kernels' records on the host for small scenes and on the device for large ones:
+    forced either way, the same kernel is picked and frames, ids, M2 and counters are identical."""
+    sc = host.Scene.from_fixture(fixture(name))
+    if quads:
+        sc.append_heightfield(quads, glass_every=16)
+    sc.build()
+    w, h, n = 96, 54, 3
+    cam = sc.camera(w, h)
+    got = {}
+    for where in ("host", "device"):
+        monkeypatch.setenv("PTX355_UPLOAD", where)
+        sc.upload_to(pt)
+        pt.enable_moments(True)
+        pt.resize(w, h)
+        pt.trace_n(cam, 0, 1, n)
+        st = pt.stats()
+        got[where] = (pt.kernel_name(), pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
+                      (st["paths"], st["bounces"], st["shadow_rays"]))
+        pt.enable_moments(False)
+    a, b = got["host"], got["device"]
+    assert a[0] == b[0] and a[5] == b[5]
+    assert same_bits(a[1], b[1]) == 0 and same_bits(a[2], b[2]) == 0 and (a[3] == b[3]).all() and (a[4] == b[4]).all()
+
+
+def test_error_reporting_of_the_device_relayout(monkeypatch):
+    monkeypatch.setenv("PTX355_UPLOAD", "device")
+    fresh = PathTracer(0)
+    sb = hp.prepare_fixture(fixture("teapot"))
+    bad = sb.prims.copy()
+    bad[5] = len(sb.figs)
+    with pytest.raises(PtxError, match="bvh_prims entry out of range"):
+        fresh.upload_scene(sb.figs, sb.mats, sb.nodes, bad, sb.lights, sb.infinite, sb.tex_pixels, sb.tex_infos)
+    figs = sb.figs.copy()
+    figs[3]["material_idx"] = len(sb.mats)
+    with pytest.raises(PtxError, match="material_idx out of range"):
+        fresh.upload_scene(figs, sb.mats, sb.nodes, sb.prims, sb.lights, sb.infinite, sb.tex_pixels, sb.tex_infos)
+    nodes = sb.nodes.copy()
+    leaf = int(np.nonzero(nodes["prim_count"] > 0)[0][0])
+    nodes[leaf]["prim_count"] = 9
+    with pytest.raises(PtxError, match="more than 7"):
+        fresh.upload_scene(sb.figs, sb.mats, nodes, sb.prims, sb.lights, sb.infinite, sb.tex_pixels, sb.tex_infos)
+    nodes = sb.nodes.copy()
+    nodes[leaf]["left_or_prim"] = len(sb.prims)
+    with pytest.raises(PtxError, match="leaf range outside"):
+        fresh.upload_scene(sb.figs, sb.mats, nodes, sb.prims, sb.lights, sb.infinite, sb.tex_pixels, sb.tex_infos)
+    nodes = sb.nodes.copy()
+    inner = int(np.nonzero(nodes["prim_count"] == 0)[0][1])
+    nodes[inner]["left_or_prim"] = inner
+    with pytest.raises(PtxError, match="child index out of order"):
+        fresh.upload_scene(sb.figs, sb.mats, nodes, sb.prims, sb.lights, sb.infinite, sb.tex_pixels, sb.tex_infos)
+    fresh.upload_scene(sb.figs, sb.mats, sb.nodes, sb.prims, sb.lights, sb.infinite, sb.tex_pixels, sb.tex_infos)  # and recovers
+    fresh.close()
+
+
 def test_error_reporting(pt):
     fresh = PathTracer(0)
     cam = hp.camera_to_gpu(hp.CameraConfig(), 8, 8)
