@@ -7,15 +7,17 @@
 #include "dmath_dev.h"
 #include "../../include/ptx355.h"
 
-#define PP_TILE 16
+#define PP_TILE 16     // a workgroup's pixels: PP_TILE columns x PP_TILE * ROWS rows, 256 threads of ROWS vertically adjacent pixels each
+#define PP_ROWS 4      // ROWS of the kernel that chains with an oil painting run (the others: 1)
 #define PP_MAX_HALO 8  // oil radii beyond this read global memory instead of the tile
 
 struct PostImage {
     const float4* accum;  // w * h
     int w, h, tx0, ty0, halo;
 };
-extern __shared__ float4 pp_tile[];  // TILE: (PP_TILE + 2 halo)^2 texels around the workgroup's pixels
-// Texel (x, y), -halo <= x - tx0 < PP_TILE + halo when the tile is used; outside the image the nearest edge texel.
+extern __shared__ float4 pp_tile[];  // TILE: (PP_TILE + 2 halo) x (PP_TILE * ROWS + 2 halo) texels around the workgroup's pixels
+// Texel (x, y), -halo <= x - tx0 < PP_TILE + halo, -halo <= y - ty0 < PP_TILE * ROWS + halo when the tile is used;
+// outside the image the nearest edge texel.
 template <bool TILE>
 PT_DEV V3 pp_read_clamped(const PostImage& im, int x, int y) {  // post_process.wgsl:37-41
     float4 a;
@@ -55,6 +57,50 @@ PT_DEV V3 pp_oil(const PostImage& im, int x, int y, int radius) {  // post_proce
     const int count = (dx1 - dx0 + 1) * (dy1 - dy0 + 1);  // > 0: the pixel itself is inside
     if (count > 0) return vdivs(total, (float)count);
     return pp_read_clamped<TILE>(im, x, y);
+}
+// The oil painting of PP_ROWS vertically adjacent pixels (x, y0 .. y0 + PP_ROWS - 1) from the tile.  Every pixel's sum
+// keeps its own order (dx outer, dy inner, ascending: float addition does not associate), but the pixels share
+// their columns: one pass down a column of PP_ROWS + 2 radius texels feeds each texel to the pixels whose window
+// holds it, 2.8 times fewer LDS reads at radius 3 than one pixel at a time.
+template <int ROWS>
+PT_DEV void pp_oil_rows(const PostImage& im, int x, int y0, int radius, V3* out) {
+    const int dx0 = -radius > -x ? -radius : -x, dx1 = radius < im.w - 1 - x ? radius : im.w - 1 - x;
+    int lo[ROWS], hi[ROWS];  // the in-image rows of each pixel's window
+    V3 total[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int y = y0 + k;
+        lo[k] = y - radius > 0 ? y - radius : 0;
+        hi[k] = y + radius < im.h - 1 ? y + radius : im.h - 1;
+        total[k] = v3(0.0f, 0.0f, 0.0f);
+    }
+    const int stride = PP_TILE + 2 * im.halo;
+    // Away from the image edge (nearly every wave) a texel's pixels depend on the row alone: scalar tests, no lane masks.
+    const bool interior = __all(x - radius >= 0 && x + radius <= im.w - 1 && y0 - radius >= 0 && y0 + ROWS - 1 + radius <= im.h - 1) != 0;
+    for (int dx = dx0; dx <= dx1; dx++) {
+        const float4* col = pp_tile + (y0 - radius - im.ty0 + im.halo) * stride + (x + dx - im.tx0 + im.halo);
+        if (interior) {
+            for (int j = 0; j < ROWS + 2 * radius; j++) {
+                const float4 a = col[j * stride];
+#pragma unroll
+                for (int k = 0; k < ROWS; k++)
+                    if (j >= k && j <= k + 2 * radius) total[k] = total[k] + v3(a.x, a.y, a.z);
+            }
+        } else {
+            for (int j = 0; j < ROWS + 2 * radius; j++) {
+                const int yy = y0 - radius + j;
+                const float4 a = col[j * stride];
+#pragma unroll
+                for (int k = 0; k < ROWS; k++)
+                    if (yy >= lo[k] && yy <= hi[k]) total[k] = total[k] + v3(a.x, a.y, a.z);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int count = (dx1 - dx0 + 1) * (hi[k] - lo[k] + 1);
+        out[k] = count > 0 ? vdivs(total[k], (float)count) : pp_read_clamped<true>(im, x, y0 + k);
+    }
 }
 template <bool TILE>
 PT_DEV V3 pp_comic(const PostImage& im, int x, int y, V3 color, uint32_t comic_levels) {  // post_process.wgsl:161-186

@@ -387,39 +387,58 @@ extern "C" __global__ void ptx_tonemap_kernel(const float4* accum, uint32_t* out
     out_rgba8[(size_t)first + i] = tonemap_rgba8(cam, v3(a.x, a.y, a.z));
 }
 
-// Post-process pass: one 16x16-pixel tile per workgroup.  TILE: the tile and a halo of `halo` texels are staged in
-// LDS (clamped to the image edge) and every effect reads from there; otherwise reads go to the accumulation buffer.
-template <bool TILE>
+// Post-process pass: one 16 x (16 ROWS)-pixel tile per workgroup, ROWS vertically adjacent pixels per thread (4 for chains
+// with an oil painting, whose pixels then share their columns; 1 otherwise: more pixels per thread cost the pointwise
+// chains 3-8 % in registers).  TILE: the tile and a halo of `halo` texels are staged in LDS (clamped to the image
+// edge) and every effect reads from there; otherwise reads go to the accumulation buffer.
+template <bool TILE, int ROWS>
 PT_DEV void post_body(const float4* accum, uint32_t* out_rgba8, const ptx_post_params pp, int halo) {
     PostImage im;
     im.accum = accum;
     im.w = (int)pp.width;
     im.h = (int)pp.height;
     im.tx0 = (int)blockIdx.x * PP_TILE;
-    im.ty0 = (int)blockIdx.y * PP_TILE;
+    im.ty0 = (int)blockIdx.y * PP_TILE * ROWS;
     im.halo = halo;
     if (TILE) {
-        const int side = PP_TILE + 2 * halo;
-        for (int i = (int)threadIdx.x; i < side * side; i += PP_TILE * PP_TILE) {
+        const int side = PP_TILE + 2 * halo, rows = PP_TILE * ROWS + 2 * halo;
+        for (int i = (int)threadIdx.x; i < side * rows; i += PP_TILE * PP_TILE) {
             int x = im.tx0 - halo + i % side, y = im.ty0 - halo + i / side;
             int cx = x < 0 ? 0 : (x > im.w - 1 ? im.w - 1 : x), cy = y < 0 ? 0 : (y > im.h - 1 ? im.h - 1 : y);
             pp_tile[i] = accum[(size_t)cy * im.w + cx];
         }
         __syncthreads();
     }
-    const int x = im.tx0 + (int)(threadIdx.x % PP_TILE), y = im.ty0 + (int)(threadIdx.x / PP_TILE);
-    if (x >= im.w || y >= im.h) return;
-    V3 result = pp_read_clamped<TILE>(im, x, y);  // post_process.wgsl:95-101
-    for (uint32_t i = 0; i < pp.effect_count; i++) result = pp_effect<TILE>(im, result, x, y, pp.effects[i], pp);
-    out_rgba8[(size_t)y * im.w + x] = unorm8(result.x) | (unorm8(result.y) << 8) | (unorm8(result.z) << 16) | 0xFF000000u;
+    const int x = im.tx0 + (int)(threadIdx.x % PP_TILE), y0 = im.ty0 + (int)(threadIdx.x / PP_TILE) * ROWS;
+    if (x >= im.w || y0 >= im.h) return;
+    V3 result[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) result[k] = pp_read_clamped<TILE>(im, x, y0 + k < im.h ? y0 + k : im.h - 1);  // post_process.wgsl:95-101
+    for (uint32_t i = 0; i < pp.effect_count; i++) {
+        if (TILE && ROWS > 1 && pp.effects[i] == 5u) {  // the oil painting shares its columns between the thread's pixels
+            pp_oil_rows<ROWS>(im, x, y0, (int)pp.oil_radius, result);
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; k++)
+            if (y0 + k < im.h) result[k] = pp_effect<TILE>(im, result[k], x, y0 + k, pp.effects[i], pp);
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; k++)
+        if (y0 + k < im.h)
+            out_rgba8[(size_t)(y0 + k) * im.w + x] = unorm8(result[k].x) | (unorm8(result[k].y) << 8) | (unorm8(result[k].z) << 16) | 0xFF000000u;
 }
 extern "C" __global__ void __launch_bounds__(PP_TILE* PP_TILE) ptx_post_kernel_tile(const float4* accum, uint32_t* out_rgba8,
                                                                                     const ptx_post_params pp, int halo) {
-    post_body<true>(accum, out_rgba8, pp, halo);
+    post_body<true, 1>(accum, out_rgba8, pp, halo);
+}
+extern "C" __global__ void __launch_bounds__(PP_TILE* PP_TILE) ptx_post_kernel_tile_rows(const float4* accum, uint32_t* out_rgba8,
+                                                                                         const ptx_post_params pp, int halo) {
+    post_body<true, PP_ROWS>(accum, out_rgba8, pp, halo);
 }
 extern "C" __global__ void __launch_bounds__(PP_TILE* PP_TILE) ptx_post_kernel(const float4* accum, uint32_t* out_rgba8,
                                                                                const ptx_post_params pp, int halo) {
-    post_body<false>(accum, out_rgba8, pp, halo);
+    post_body<false, 1>(accum, out_rgba8, pp, halo);
 }
 
 extern "C" __global__ void ptx_kat_math_kernel(int op, uint32_t n, const float* a, const float* b, float* out) {
@@ -1405,10 +1424,14 @@ int ptx_post_process(ptx_ctx* c, const ptx_post_params* pp) {
         if (e == 5u) halo = halo < pp->oil_radius ? pp->oil_radius : halo;
     }
     if (halo > 0x3FFFFFFFu) return fail(c, PTX_ERR_BAD_ARG, "oil_radius too large");
-    const dim3 grid((c->w + PP_TILE - 1u) / PP_TILE, (c->h + PP_TILE - 1u) / PP_TILE), block(PP_TILE * PP_TILE);
+    bool oil = false;
+    for (uint32_t i = 0; i < pp->effect_count; i++) oil = oil || pp->effects[i] == 5u;
+    const uint32_t rows_per_thread = oil && halo <= PP_MAX_HALO ? (uint32_t)PP_ROWS : 1u, tile_h = PP_TILE * rows_per_thread;
+    const dim3 grid((c->w + PP_TILE - 1u) / PP_TILE, (c->h + tile_h - 1u) / tile_h), block(PP_TILE * PP_TILE);
     if (halo <= PP_MAX_HALO) {
-        const size_t side = PP_TILE + 2u * halo;
-        hipLaunchKernelGGL(ptx_post_kernel_tile, grid, block, side * side * sizeof(float4), c->stream, c->accum, c->out, *pp, (int)halo);
+        const size_t lds = (PP_TILE + 2u * halo) * (tile_h + 2u * halo) * sizeof(float4);
+        if (rows_per_thread > 1u) hipLaunchKernelGGL(ptx_post_kernel_tile_rows, grid, block, lds, c->stream, c->accum, c->out, *pp, (int)halo);
+        else hipLaunchKernelGGL(ptx_post_kernel_tile, grid, block, lds, c->stream, c->accum, c->out, *pp, (int)halo);
     } else {
         hipLaunchKernelGGL(ptx_post_kernel, grid, block, 0, c->stream, c->accum, c->out, *pp, (int)halo);
     }
