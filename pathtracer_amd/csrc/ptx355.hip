@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <chrono>
 #include <vector>
 #include "sched_dev.h"

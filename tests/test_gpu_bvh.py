@@ -41,7 +41,7 @@ def test_small_sets_equal_the_restatement(pt, name):
     _check(pt, aabbs, hp.bvh_build([(b[:3].copy(), b[3:].copy()) for b in aabbs]))
 
 
-@pytest.mark.parametrize("n", [2, 3, 6, 9, 63, 64, 65, 255, 256, 257, 258, 511, 513, 1000, 4097, 20000])
+@pytest.mark.parametrize("n", [2, 3, 6, 9, 63, 64, 65, 255, 256, 257, 258, 511, 513, 1000, 4097, 8191, 8192, 8193, 8200, 16385, 20000])
 def test_random_boxes_around_the_wave_and_range_limits(pt, n):
     _check(pt, random_boxes(n, n))
 
