@@ -63,6 +63,12 @@ int pth_scene_provide_texture(pth_scene* s, uint32_t i, const uint8_t* rgba8, ui
  * src/accel/aabb.rs; src/io/texture_atlas.rs).  Must be called before the getters below. */
 int pth_scene_build(pth_scene* s);
 
+/* AppState::save_scene + scene::exporter::save_scene (src/app/scene_ops.rs:115-124, src/scene/exporter.rs:11-70): writes the
+ * camera block and every shape (model triangles included: the reference saves its expanded list with `models: []`) as
+ * YAML, fields at their serde default left out, numeric arrays in flow style.  Per-vertex UVs are not written
+ * (shape.rs:169-175).  pth_scene_load reads the file back to the same scene.  0, or -2 when the file cannot be written. */
+int pth_scene_save(const pth_scene* s, const char* yaml_path);
+
 /* A BVH builder over n primitive boxes (n x {min xyz, max xyz}): fills max(1, 2n) nodes / n primitive positions
  * and returns 0.  pth_bvh_build is Bvh::build (src/accel/bvh.rs:37-213) on the host; the device library's
  * ptx_bvh_build has the same signature with its context as `user` and gives the same arrays. */

@@ -4,6 +4,7 @@
 #include "../../../include/pth_host.h"
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@ struct Material {
     }
 };
 struct Shape {
+    std::string name;  // empty = none
     uint32_t type = 0;
     bool negative = false;
     float position[3] = {0, 0, 0}, normal[3] = {0, 1, 0};
@@ -235,6 +237,7 @@ YNode parse_value(const std::string& v) {
     YNode n;
     std::string t = trim(v);
     if (t.empty() || t == "~" || t == "null") return n;
+    if (t == "{}") { n.kind = YNode::Map; return n; }  // an empty flow mapping: what serde writes for a struct with every field skipped
     if (t.front() == '[') {
         n.kind = YNode::Seq;
         size_t e = t.rfind(']');
@@ -330,6 +333,9 @@ bool parse_yaml_file(const std::string& path, YNode& out, std::string& err) {
 // serde: YAML number -> f64 -> `as f32`.
 bool y_f32(const YNode* n, float& v) {
     if (!n || n->kind != YNode::Scalar) return false;
+    if (n->s == ".inf" || n->s == "+.inf") { v = INF; return true; }   // YAML 1.2 core schema spellings
+    if (n->s == "-.inf") { v = -INF; return true; }
+    if (n->s == ".nan") { v = std::numeric_limits<float>::quiet_NaN(); return true; }
     char* e = nullptr;
     double d = std::strtod(n->s.c_str(), &e);
     if (e == n->s.c_str()) return false;
@@ -609,6 +615,7 @@ pth_scene* pth_scene_load(const char* yaml_path, const char* resource_root, char
             if (ty) for (int i = 0; i < 17; i++) if (ty->s == TYPE_NAMES[i]) tid = i;
             if (tid < 0) { pth_scene_free(s); return bail("unknown or missing shape type '" + (ty ? ty->s : "") + "'"); }
             sh.type = (uint32_t)tid;
+            if (const YNode* nm = n.get("name"); nm && nm->kind == YNode::Scalar) sh.name = nm->s;
             if (const YNode* ng = n.get("negative")) sh.negative = ng->s == "true";
             y_vec(n.get("position"), sh.position, 3);
             y_vec(n.get("normal"), sh.normal, 3);
@@ -645,6 +652,108 @@ pth_scene* pth_scene_load(const char* yaml_path, const char* resource_root, char
     return s;
 }
 
+// ---- scene export (src/scene/exporter.rs:11-70, src/app/scene_ops.rs:115-124) ----------------------------------------
+namespace {
+// An f32 as the shortest decimal that reads back to the same value, always with a fraction or an exponent
+// (serde_yml prints floats through ryu: 1.0, 0.8, 1e-5), YAML spellings for the non-finite values.
+std::string yaml_f32(float v) {
+    if (v != v) return ".nan";
+    if (v == INF) return ".inf";
+    if (v == -INF) return "-.inf";
+    char buf[48];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    std::string t(buf, r.ptr);
+    if (t.find_first_of(".en") == std::string::npos) t += ".0";
+    return t;
+}
+std::string yaml_vec3(const float* v) { return "[" + yaml_f32(v[0]) + ", " + yaml_f32(v[1]) + ", " + yaml_f32(v[2]) + "]"; }
+// A plain scalar when that is unambiguous, else double-quoted.
+std::string yaml_str(const std::string& v) {
+    bool plain = !v.empty() && v.find_first_of(":#[]{},&*!|>'\"%@`\n\t") == std::string::npos && v.front() != ' ' && v.back() != ' ' &&
+                 v.front() != '-' && v.front() != '?';
+    if (plain) {
+        char* e = nullptr;
+        (void)std::strtod(v.c_str(), &e);
+        if (*e == '\0' || v == "true" || v == "false" || v == "null" || v == "~" || v == "yes" || v == "no") plain = false;
+    }
+    if (plain) return v;
+    std::string q = "\"";
+    for (char ch : v) {
+        if (ch == '"' || ch == '\\') q += '\\';
+        if (ch == '\n') { q += "\\n"; continue; }
+        q += ch;
+    }
+    return q + "\"";
+}
+bool zero3(const float* v) { return v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f; }
+bool eq3(const float* v, float a, float b, float c) { return v[0] == a && v[1] == b && v[2] == c; }
+bool material_is_default(const Material& m) {  // material.rs:102-104
+    return eq3(m.base_color, 0.8f, 0.8f, 0.8f) && m.metallic == 0.0f && m.roughness == 0.5f && zero3(m.emission) &&
+           m.emission_strength == 0.0f && m.ior == 1.5f && m.transmission == 0.0f && m.texture_id == -1;
+}
+}  // namespace
+
+// AppState::save_scene + exporter::save_scene: the camera block and every shape (model triangles included, as the
+// reference saves its expanded shape list with `models: []`), fields at their serde default left out
+// (scene.rs:72-141, shape.rs:104-176, material.rs:9-39), numeric arrays in flow style (collapse_block_arrays).
+// Per-vertex UVs are not written (shape.rs:169-175: skip_serializing).
+int pth_scene_save(const pth_scene* s, const char* yaml_path) {
+    if (!s || !yaml_path) return -1;
+    std::ofstream f(yaml_path);
+    if (!f) return -2;
+    const CameraConfig& c = s->camera;
+    const CameraConfig d;
+    std::string cam;
+    if (!zero3(c.position)) cam += "  position: " + yaml_vec3(c.position) + "\n";
+    if (!zero3(c.rotation)) cam += "  rotation: " + yaml_vec3(c.rotation) + "\n";
+    if (c.fov != d.fov) cam += "  fov: " + yaml_f32(c.fov) + "\n";
+    if (c.exposure != d.exposure) cam += "  exposure: " + yaml_f32(c.exposure) + "\n";
+    if (c.max_bounces != d.max_bounces) cam += "  max_bounces: " + std::to_string(c.max_bounces) + "\n";
+    if (c.firefly_clamp != d.firefly_clamp) cam += "  firefly_clamp: " + yaml_f32(c.firefly_clamp) + "\n";
+    if (!eq3(c.skybox_color, d.skybox_color[0], d.skybox_color[1], d.skybox_color[2])) cam += "  skybox_color: " + yaml_vec3(c.skybox_color) + "\n";
+    if (c.skybox_brightness != d.skybox_brightness) cam += "  skybox_brightness: " + yaml_f32(c.skybox_brightness) + "\n";
+    if (c.tone_mapper != d.tone_mapper) cam += "  tone_mapper: " + std::to_string(c.tone_mapper) + "\n";
+    if (c.fractal_march_steps != d.fractal_march_steps) cam += "  fractal_march_steps: " + std::to_string(c.fractal_march_steps) + "\n";
+    f << (cam.empty() ? "camera: {}\n" : "camera:\n" + cam);
+    if (s->shapes.empty()) f << "shapes: []\n";
+    else f << "shapes:\n";
+    for (const Shape& sh : s->shapes) {
+        std::string o;
+        auto field = [&](const std::string& line) { o += (o.empty() ? "- " : "  ") + line + "\n"; };
+        if (!sh.name.empty()) field("name: " + yaml_str(sh.name));
+        field(std::string("type: ") + (sh.type < 17u ? TYPE_NAMES[sh.type] : "sphere"));
+        if (sh.negative) field("negative: true");
+        if (!zero3(sh.position)) field("position: " + yaml_vec3(sh.position));
+        if (!eq3(sh.normal, 0.0f, 1.0f, 0.0f)) field("normal: " + yaml_vec3(sh.normal));
+        if (sh.radius != 1.0f) field("radius: " + yaml_f32(sh.radius));
+        if (sh.radius2 != 0.0f) field("radius2: " + yaml_f32(sh.radius2));
+        if (sh.height != 0.0f) field("height: " + yaml_f32(sh.height));
+        if (!zero3(sh.rotation)) field("rotation: " + yaml_vec3(sh.rotation));
+        if (!zero3(sh.v0)) field("v0: " + yaml_vec3(sh.v0));
+        if (!zero3(sh.v1)) field("v1: " + yaml_vec3(sh.v1));
+        if (!zero3(sh.v2)) field("v2: " + yaml_vec3(sh.v2));
+        if (sh.power != 8.0f) field("power: " + yaml_f32(sh.power));
+        if (sh.max_iterations != 12u) field("max_iterations: " + std::to_string(sh.max_iterations));
+        if (!sh.texture.empty()) field("texture: " + yaml_str(sh.texture));
+        if (sh.has_texture_scale) field("texture_scale: " + yaml_f32(sh.texture_scale));
+        const Material& m = sh.material;
+        if (!material_is_default(m)) {
+            field("material:");
+            if (!eq3(m.base_color, 0.8f, 0.8f, 0.8f)) field("  base_color: " + yaml_vec3(m.base_color));
+            if (m.metallic != 0.0f) field("  metallic: " + yaml_f32(m.metallic));
+            if (m.roughness != 0.5f) field("  roughness: " + yaml_f32(m.roughness));
+            if (!zero3(m.emission)) field("  emission: " + yaml_vec3(m.emission));
+            if (m.emission_strength != 0.0f) field("  emission_strength: " + yaml_f32(m.emission_strength));
+            if (m.ior != 1.5f) field("  ior: " + yaml_f32(m.ior));
+            if (m.transmission != 0.0f) field("  transmission: " + yaml_f32(m.transmission));
+            if (m.texture_id != -1) field("  texture_id: " + std::to_string(m.texture_id));
+        }
+        f << o;
+    }
+    f.flush();
+    return f ? 0 : -2;
+}
+
 int pth_scene_append_shapes(pth_scene* s, const ptx_shape* figs, const ptx_material* mats, uint32_t n) {
     if (!s || (n && (!figs || !mats))) return -1;
     for (uint32_t i = 0; i < n; i++) {
@@ -659,7 +768,7 @@ int pth_scene_append_shapes(pth_scene* s, const ptx_shape* figs, const ptx_mater
         memcpy(sh.rotation, f.rotation, 12);
         memcpy(sh.v0, f.v0, 12); memcpy(sh.v1, f.v1, 12); memcpy(sh.v2, f.v2, 12);
         if (f.shape_type == 9u || f.shape_type == 10u) { sh.power = f.v0[0]; sh.max_iterations = (uint32_t)f.v0[1]; }
-        sh.has_texture_scale = true;
+        sh.has_texture_scale = f.texture_scale != 1.0f;  // the record holds texture_scale.unwrap_or(1.0): 1.0 reads back as None
         sh.texture_scale = f.texture_scale;
         {   // binary16 -> f32 is exact and the build's truncating f32 -> binary16 restores the same bits
             auto h2f = [](uint32_t h) {

@@ -23,6 +23,7 @@ class PthAccumulator(C.Structure):
 SYMBOLS = [
     ("pth_scene_load", _P, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("pth_scene_new", _P, []),
+    ("pth_scene_save", C.c_int, [_P, C.c_char_p]),
     ("pth_scene_free", None, [_P]),
     ("pth_last_error", C.c_char_p, [_P]),
     ("pth_scene_append_shapes", C.c_int, [_P, _P, _P, _U]),
@@ -106,6 +107,11 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def save(self, yaml_path: str):
+        """AppState::save_scene (src/app/scene_ops.rs:115-124): camera + every shape as YAML."""
+        if self.lib.pth_scene_save(self.h, yaml_path.encode()) != 0:
+            raise RuntimeError(f"pth_scene_save({yaml_path}) failed")
 
     def append_shapes(self, figs: np.ndarray, mats: np.ndarray):
         figs = np.ascontiguousarray(figs, dtype=SHAPE_DT)
