@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "lib")
 CSRC = os.path.join(HERE, "csrc")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
-HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall", "-pthread"]
 
 
 def _stale(target: str, deps) -> bool:

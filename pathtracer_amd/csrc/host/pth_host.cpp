@@ -14,6 +14,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -938,61 +939,86 @@ int pth_scene_build_with(pth_scene* s, pth_bvh_fn bvh, void* user) {
         s->tex_infos.push_back(ti);
         s->tex_pixels.insert(s->tex_pixels.end(), s->tex[i].px.begin(), s->tex[i].px.end());
     }
-    // state.rs:350-377
+    // state.rs:350-377 (records) and 543-567 (finite / plane split, boxes).  Every shape is independent; large scenes
+    // are packed by several threads, each over a contiguous slice, the per-slice index lists joined in slice order.
     size_t n = s->shapes.size();
-    s->figs.assign(n, ptx_shape{});
-    s->mats.assign(n, ptx_material{});
-    s->lights.clear();
-    for (size_t i = 0; i < n; i++) {
-        const Shape& sh = s->shapes[i];
-        ptx_material& m = s->mats[i];  // material.rs:121-134
-        memcpy(m.base_color, sh.material.base_color, 12);
-        m.metallic = sh.material.metallic;
-        memcpy(m.emission, sh.material.emission, 12);
-        m.roughness = std::fmax(sh.material.roughness, 0.04f);
-        m.emission_strength = sh.material.emission_strength;
-        m.ior = sh.material.ior;
-        m.transmission = sh.material.transmission;
-        m.texture_id = sh.material.texture_id;
-        if (!sh.texture.empty() && cache.count(sh.texture)) m.texture_id = cache[sh.texture];
-        ptx_shape& g = s->figs[i];  // shape.rs:251-278
-        g.shape_type = sh.type;
-        g.material_idx = (uint32_t)i;
-        g.radius = sh.radius; g.radius2 = sh.radius2; g.height = sh.height;
-        memcpy(g.position, sh.position, 12);
-        {   // glam Vec3::normalize_or_zero
-            float x = sh.normal[0], y = sh.normal[1], z = sh.normal[2];
-            float d = x * x + y * y + z * z;
-            float rcp = 1.0f / std::sqrt(d);
-            if (std::isfinite(rcp) && rcp > 0.0f) { g.normal[0] = x * rcp; g.normal[1] = y * rcp; g.normal[2] = z * rcp; }
-            else { g.normal[0] = g.normal[1] = g.normal[2] = 0.0f; }
+    s->figs.resize(n);
+    s->mats.resize(n);
+    size_t n_slices = n < 65536 ? 1 : std::min<size_t>(16, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("PTH_BUILD_THREADS")) n_slices = std::min<size_t>(64, std::max(1, atoi(e)));  // tests, measurements
+    struct Slice { std::vector<uint32_t> lights, infinite, finite; };
+    std::vector<Slice> slices(n_slices);
+    auto pack = [&](size_t si) {
+        Slice& out = slices[si];
+        const size_t i0 = n * si / n_slices, i1 = n * (si + 1) / n_slices;
+        for (size_t i = i0; i < i1; i++) {
+            const Shape& sh = s->shapes[i];
+            ptx_material m{};  // material.rs:121-134
+            memcpy(m.base_color, sh.material.base_color, 12);
+            m.metallic = sh.material.metallic;
+            memcpy(m.emission, sh.material.emission, 12);
+            m.roughness = std::fmax(sh.material.roughness, 0.04f);
+            m.emission_strength = sh.material.emission_strength;
+            m.ior = sh.material.ior;
+            m.transmission = sh.material.transmission;
+            m.texture_id = sh.material.texture_id;
+            if (!sh.texture.empty()) {
+                auto it = cache.find(sh.texture);
+                if (it != cache.end()) m.texture_id = it->second;
+            }
+            s->mats[i] = m;
+            ptx_shape g{};  // shape.rs:251-278
+            g.shape_type = sh.type;
+            g.material_idx = (uint32_t)i;
+            g.radius = sh.radius; g.radius2 = sh.radius2; g.height = sh.height;
+            memcpy(g.position, sh.position, 12);
+            {   // glam Vec3::normalize_or_zero
+                float x = sh.normal[0], y = sh.normal[1], z = sh.normal[2];
+                float d = x * x + y * y + z * z;
+                float rcp = 1.0f / std::sqrt(d);
+                if (std::isfinite(rcp) && rcp > 0.0f) { g.normal[0] = x * rcp; g.normal[1] = y * rcp; g.normal[2] = z * rcp; }
+                else { g.normal[0] = g.normal[1] = g.normal[2] = 0.0f; }
+            }
+            g.csg_op = sh.negative ? 1u : 0u;
+            memcpy(g.rotation, sh.rotation, 12);
+            g.texture_scale = sh.has_texture_scale ? sh.texture_scale : 1.0f;
+            if (sh.type == 9u || sh.type == 10u) { g.v0[0] = sh.power; g.v0[1] = (float)sh.max_iterations; g.v0[2] = 0.0f; }
+            else memcpy(g.v0, sh.v0, 12);
+            memcpy(g.v1, sh.v1, 12);
+            memcpy(g.v2, sh.v2, 12);
+            g._pad2 = (uint32_t)pth_f32_to_f16_bits(sh.uv0[0]) | ((uint32_t)pth_f32_to_f16_bits(sh.uv0[1]) << 16);
+            g._pad3 = (uint32_t)pth_f32_to_f16_bits(sh.uv1[0]) | ((uint32_t)pth_f32_to_f16_bits(sh.uv1[1]) << 16);
+            g._pad4 = (uint32_t)pth_f32_to_f16_bits(sh.uv2[0]) | ((uint32_t)pth_f32_to_f16_bits(sh.uv2[1]) << 16);
+            s->figs[i] = g;
+            if (sh.material.is_emissive()) out.lights.push_back((uint32_t)i);
+            if (sh.type == 1u) out.infinite.push_back((uint32_t)i);
+            else if (sh.type != 8u) out.finite.push_back((uint32_t)i);
         }
-        g.csg_op = sh.negative ? 1u : 0u;
-        memcpy(g.rotation, sh.rotation, 12);
-        g.texture_scale = sh.has_texture_scale ? sh.texture_scale : 1.0f;
-        if (sh.type == 9u || sh.type == 10u) { g.v0[0] = sh.power; g.v0[1] = (float)sh.max_iterations; g.v0[2] = 0.0f; }
-        else memcpy(g.v0, sh.v0, 12);
-        memcpy(g.v1, sh.v1, 12);
-        memcpy(g.v2, sh.v2, 12);
-        g._pad2 = (uint32_t)pth_f32_to_f16_bits(sh.uv0[0]) | ((uint32_t)pth_f32_to_f16_bits(sh.uv0[1]) << 16);
-        g._pad3 = (uint32_t)pth_f32_to_f16_bits(sh.uv1[0]) | ((uint32_t)pth_f32_to_f16_bits(sh.uv1[1]) << 16);
-        g._pad4 = (uint32_t)pth_f32_to_f16_bits(sh.uv2[0]) | ((uint32_t)pth_f32_to_f16_bits(sh.uv2[1]) << 16);
-        if (sh.material.is_emissive()) s->lights.push_back((uint32_t)i);
-    }
-    // state.rs:543-567
+    };
+    auto run_slices = [&](auto&& fn) {
+        if (n_slices == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (size_t si = 0; si < n_slices; si++) th.emplace_back(fn, si);
+        for (auto& t : th) t.join();
+    };
+    run_slices(pack);
     std::vector<uint32_t> finite;
+    s->lights.clear();
     s->infinite.clear();
-    for (size_t i = 0; i < n; i++) {
-        if (s->shapes[i].type == 1u) s->infinite.push_back((uint32_t)i);
-        else if (s->shapes[i].type == 8u) {}
-        else finite.push_back((uint32_t)i);
+    for (const Slice& sl : slices) {
+        s->lights.insert(s->lights.end(), sl.lights.begin(), sl.lights.end());
+        s->infinite.insert(s->infinite.end(), sl.infinite.begin(), sl.infinite.end());
+        finite.insert(finite.end(), sl.finite.begin(), sl.finite.end());
     }
     std::vector<float> boxes(finite.size() * 6);
-    for (size_t k = 0; k < finite.size(); k++) {
-        Aabb b = shape_aabb(s->shapes[finite[k]]);
-        float* o = boxes.data() + k * 6;
-        o[0] = b.mn.x; o[1] = b.mn.y; o[2] = b.mn.z; o[3] = b.mx.x; o[4] = b.mx.y; o[5] = b.mx.z;
-    }
+    run_slices([&](size_t si) {
+        const size_t k0 = finite.size() * si / n_slices, k1 = finite.size() * (si + 1) / n_slices;
+        for (size_t k = k0; k < k1; k++) {
+            Aabb b = shape_aabb(s->shapes[finite[k]]);
+            float* o = boxes.data() + k * 6;
+            o[0] = b.mn.x; o[1] = b.mn.y; o[2] = b.mn.z; o[3] = b.mx.x; o[4] = b.mx.y; o[5] = b.mx.z;
+        }
+    });
     s->nodes.assign(std::max<size_t>(1, 2 * finite.size()), ptx_bvh_node{});
     s->prims.assign(finite.size(), 0u);
     uint32_t n_nodes = 0;

@@ -118,3 +118,18 @@ def test_accumulator_and_frame_indices():
     lib = host.load()
     assert lib.pth_dispatch_size(1920, 8) == 240 and lib.pth_dispatch_size(1081, 8) == 136
     assert lib.pth_f32_to_f16_bits(1.0) == 0x3C00
+
+
+def test_scene_build_is_the_same_with_any_number_of_packing_threads(monkeypatch):
+    """pth_scene_build packs large scenes with several threads over contiguous slices: 1, 3 and 7 slices give the same buffers
+    (light, plane and BVH-primitive lists in figure order included)."""
+    got = []
+    for threads in ("1", "3", "7"):
+        monkeypatch.setenv("PTH_BUILD_THREADS", threads)
+        sc = host.Scene.from_fixture(fixture("all"))
+        sc.append_heightfield(30, glass_every=8)
+        sc.build(decode_textures=False)
+        b = sc.buffers()
+        got.append({k: v.tobytes() for k, v in b.items()})
+    assert got[0] == got[1] == got[2]
+    assert len(got[0]["figs"]) // 112 == 14 + 2 * 30 * 30
