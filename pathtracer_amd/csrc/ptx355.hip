@@ -237,6 +237,15 @@ PT_DEV void sched_body(const TraceParams& P) {
     px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
     px_u[6 * 64] = 0u;  // samples of the current pixel finished
     px_u[7 * 64] = 0u;  // path-bounces, all pixels of this lane
+    // FRAC: which lanes of each wave stand in an estimator (republished every scheduling round), for the other waves'
+    // idle lanes to take evaluations from (sched_dev.h, FS_*); every status word starts idle before any wave looks.
+    __shared__ unsigned long long est_lanes[2][PTX_WAVES_PER_BLOCK];
+    if (FRAC) {
+        ((uint32_t*)frac)[FR_STATUS * 64] = FS_IDLE;
+        if (lane == 0u) { est_lanes[0][wave] = 0ull; est_lanes[1][wave] = 0ull; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __syncthreads();
+    }
     uint32_t n_shadow = 0;
     Trav tv;
     tv.ray.o = v3(0.0f, 0.0f, 0.0f);
@@ -272,6 +281,10 @@ PT_DEV void sched_body(const TraceParams& P) {
             if (pop[s] > fullest_n) { fullest_n = pop[s]; fullest = s; }
             if (s >= (uint32_t)LS_TORUS && s <= (uint32_t)LS_JULIA && pop[s] > march_n) { march_n = pop[s]; march = s; }
         }
+        if (FRAC) {
+            const unsigned long long in_mandel = __ballot(S == LS_MANDEL), in_julia = __ballot(S == LS_JULIA);
+            if (lane == 0u) { est_lanes[0][wave] = in_mandel; est_lanes[1][wave] = in_julia; }
+        }
         if (live == 0u) break;
         const uint32_t single = P.walk_single;  // WALK mode
         uint32_t pick = fullest;
@@ -302,8 +315,30 @@ PT_DEV void sched_body(const TraceParams& P) {
                     PT_SITE_ADD(73, (uint32_t)__popcll(__ballot(S == LS_JULIA)));
                     PT_SITE_ADD(74, (uint32_t)__popcll(__ballot(S == LS_IDLE)));
                 }
-                if (S == pick) S = (FRAC && pick >= (uint32_t)LS_MANDEL) ? frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park, single)
-                                                                        : march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
+                if (FRAC && pick >= (uint32_t)LS_MANDEL) {
+                    // this wave's lanes outside the estimator run an iteration each for lanes of the workgroup's other waves
+                    // that stand in it: the r-th idle lane takes the r-th such lane, counted from the next wave round
+                    const unsigned long long idle = __ballot(S != pick);
+                    float* theirs = nullptr;
+                    if (S != pick) {
+                        uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        for (uint32_t k = 1u; k < (uint32_t)PTX_WAVES_PER_BLOCK; k++) {
+                            const uint32_t w2 = (wave + k) % (uint32_t)PTX_WAVES_PER_BLOCK;
+                            const unsigned long long m2 = est_lanes[pick - (uint32_t)LS_MANDEL][w2];
+                            const uint32_t c2 = (uint32_t)__popcll(m2);
+                            if (r < c2) {
+                                theirs = fields + (size_t)w2 * kFields * 64u + (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u + nth_set_bit(m2, r);
+                                break;
+                            }
+                            r -= c2;
+                        }
+                    }
+                    float* st = S == pick ? frac : theirs;
+                    if (st) (void)frac_iterate(sc, st);  // one pass of the estimator's code for own and adopted evaluations alike
+                    if (S == pick) S = frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park, single);
+                } else if (S == pick) {
+                    S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
+                }
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
                 if (m == 0u || m * 4u < n0 * 3u) break;
             }

@@ -60,8 +60,17 @@ enum : uint32_t {
     PK_WO = 21
 };
 // Kernels with the fractal code: the estimator's iteration state (FracIter) follows the parked fields.
-#define SC_FRAC_FIELDS 10u   // FracIter::s[0..8], iterations done | phase << 16
-enum : uint32_t { FR_S = 0, FR_I = 9 };
+#define SC_FRAC_FIELDS 12u   // FracIter::s[0..8], iterations done | phase << 16, the figure's primitive slot, the evaluation's status
+enum : uint32_t { FR_S = 0, FR_I = 9, FR_REF = 10, FR_STATUS = 11 };
+// An evaluation's status word.  An evaluation is a pure function of its state (FracIter + the figure), and the state
+// lives in LDS, so ANY lane of the workgroup may run its iterations: a wave serving an estimator has most of its lanes
+// idle (they wait in other states), and those lanes take over evaluations of the workgroup's other waves.  Whoever
+// runs an iteration first claims the state (READY -> BUSY) and hands it back (READY, or DONE with the value in
+// FR_S); only the lane that owns the evaluation acts on the result.  The arithmetic does not depend on who ran it.
+enum : uint32_t { FS_IDLE = 0, FS_READY = 1, FS_BUSY = 2, FS_DONE = 3 };
+#ifndef FRAC_ITERS_PER_CLAIM
+#define FRAC_ITERS_PER_CLAIM 6
+#endif
 // What a fractal evaluation is for: a marching step, the second evaluation of an over-relaxed step, or one of
 // the four evaluations of the winner's normal (torus.wgsl:54-61 pattern in mandelbulb.wgsl:83-93 / julia.wgsl:83-93).
 enum : uint32_t { FP_D = 0, FP_D2 = 1, FP_N0 = 2, FP_N1 = 3, FP_N2 = 4, FP_N3 = 5 };
@@ -117,16 +126,63 @@ PT_DEV bool trav_apply(const DScene& sc, Trav& tv, bool hit, float ht, uint32_t 
 // primitives of its leaf to test waits for the next LEAF round, otherwise it walks on.
 PT_DEV uint32_t after_prim(const Trav& tv, uint32_t mode) { return mode != 0u && tv.pi < tv.pend ? (uint32_t)LS_LEAF : (uint32_t)LS_WALK; }
 
-// Starts an estimator evaluation at the point of `ray` at distance t (+ `offset`, in the figure's unit space).
-PT_DEV void frac_start(const DPrim& g, const Ray& ray, float t, uint32_t phase, V3 offset, float* frac) {
+// This wave's LDS operations have completed (the compiler puts no such wait before a workgroup-scope release).
+PT_DEV void lds_drain() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+// Starts an estimator evaluation at the point of `ray` at distance t (+ `offset`, in the figure's unit space);
+// `ref` is the figure's primitive slot (slot_prim).
+PT_DEV void frac_start(const DPrim& g, uint32_t ref, const Ray& ray, float t, uint32_t phase, V3 offset, float* frac) {
     const float inv_radius = dm::rcp_(g.p[3]);
     V3 p = (madd(ray.o, ray.d, t) - v3p(g.p)) * inv_radius;  // march_fractal: p * inv_radius; finish_fractal: local
     if (phase >= FP_N0) p = p + offset;
     FracIter f;
     frac_eval_begin(g, p, f);
+    uint32_t* frac_u = (uint32_t*)frac;
 #pragma unroll
     for (int k = 0; k < 9; k++) frac[(FR_S + k) * 64] = f.s[k];
-    ((uint32_t*)frac)[FR_I * 64] = f.i | (phase << 16);
+    frac_u[FR_I * 64] = f.i | (phase << 16);
+    frac_u[FR_REF * 64] = ref;
+    lds_drain();
+    __hip_atomic_store(&frac_u[FR_STATUS * 64], (uint32_t)FS_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// One iteration of the evaluation whose state is at `st` (this lane's own or another lane's), if nobody else holds it.
+PT_DEV bool frac_iterate(const DScene& sc, float* st) {
+    uint32_t* su = (uint32_t*)st;
+    uint32_t expected = FS_READY;
+    if (!__hip_atomic_compare_exchange_strong(&su[FR_STATUS * 64], &expected, (uint32_t)FS_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP))
+        return false;
+    const uint32_t word = su[FR_I * 64];
+    const DPrim& g = slot_prim(sc, su[FR_REF * 64]);
+    FracIter f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) f.s[k] = st[(FR_S + k) * 64];
+    f.i = word & 0xFFFFu;
+    float value;
+    uint32_t next = FS_READY;
+    bool done = false;
+    for (int it = 0; it < FRAC_ITERS_PER_CLAIM && !done; it++) done = frac_eval_iter(g, f, value);  // a claim is amortised over a few iterations
+    if (!done) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) st[(FR_S + k) * 64] = f.s[k];
+        su[FR_I * 64] = f.i | (word & 0xFFFF0000u);
+    } else {
+        st[FR_S * 64] = value;
+        next = FS_DONE;
+    }
+    lds_drain();
+    __hip_atomic_store(&su[FR_STATUS * 64], next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+}
+// The r-th set bit of m (r < popcount(m)).
+PT_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
+    uint32_t pos = 0u;
+#pragma unroll
+    for (uint32_t w = 32u; w >= 1u; w >>= 1) {
+        const uint32_t c = (uint32_t)__popcll((m >> pos) & ((1ull << w) - 1ull));
+        if (r >= c) { r -= c; pos += w; }
+    }
+    return pos;
 }
 PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yxy, e.xxx with e = (k, -k)
     switch (k_index) {
@@ -138,23 +194,17 @@ PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yx
 }
 // One step of a lane inside a fractal estimator: one iteration and, when the evaluation completes, what the
 // evaluation was for (march_step_fractal's logic around its two sdf calls, or finish_fractal's normal).
+// (The iteration itself is frac_iterate, which the scheduler runs for this lane's evaluation and, in the same
+// instruction stream, for the evaluations its idle lanes have taken over.)
 PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park, uint32_t mode) {
     PT_SITE(42);
     uint32_t* frac_u = (uint32_t*)frac;
     uint32_t* park_u = (uint32_t*)park;
-    const uint32_t word = frac_u[FR_I * 64], phase = word >> 16;
-    const DPrim& g = phase >= FP_N0 ? slot_prim(sc, tv.slot) : sc.prims[tv.pi];
-    FracIter f;
-#pragma unroll
-    for (int k = 0; k < 9; k++) f.s[k] = frac[(FR_S + k) * 64];
-    f.i = word & 0xFFFFu;
-    float value;
-    if (!frac_eval_iter(g, f, value)) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) frac[(FR_S + k) * 64] = f.s[k];
-        frac_u[FR_I * 64] = f.i | (phase << 16);
-        return kind;
-    }
+    if (__hip_atomic_load(&frac_u[FR_STATUS * 64], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)FS_DONE) return kind;
+    const uint32_t phase = frac_u[FR_I * 64] >> 16, ref = frac_u[FR_REF * 64];
+    const float value = frac[FR_S * 64];
+    frac_u[FR_STATUS * 64] = FS_IDLE;
+    const DPrim& g = slot_prim(sc, ref);
     if (phase >= FP_N0) {  // finish_fractal / tet_normal: normalize(o0 d0 + o1 d1 + o2 d2 + o3 d3), summed left to right
         const float k = 0.5773f * PT_EPS * 2.0f;
         const uint32_t idx = phase - FP_N0;
@@ -166,7 +216,7 @@ PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t ma
         }
         park[(PK_N + 0) * 64] = acc.x; park[(PK_N + 1) * 64] = acc.y; park[(PK_N + 2) * 64] = acc.z;
         if (idx == 3u) return LS_POST;
-        frac_start(g, tv.ray, tv.bound, phase + 1u, tet_offset(idx + 1u, k), frac);
+        frac_start(g, ref, tv.ray, tv.bound, phase + 1u, tet_offset(idx + 1u, k), frac);
         return kind;
     }
     // march_step_fractal around the evaluation that just completed
@@ -178,7 +228,7 @@ PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t ma
         float d = value * radius;
         if (d < 0.0f && m.prev_d > 0.0f) {
             m.t -= m.prev_d * (omega - 1.0f);
-            frac_start(g, tv.ray, m.t, FP_D2, v3(0.0f, 0.0f, 0.0f), frac);
+            frac_start(g, ref, tv.ray, m.t, FP_D2, v3(0.0f, 0.0f, 0.0f), frac);
             return kind;
         }
         if (dm::abs_(d) < PT_EPS * m.t * 0.5f) r = MARCH_HIT;
@@ -195,7 +245,7 @@ PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t ma
     if (r == MARCH_GO) {
         m.i += 1u;
         if (m.i < march_steps) {
-            frac_start(g, tv.ray, m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
+            frac_start(g, ref, tv.ray, m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
             return kind;
         }
         r = MARCH_MISS;
@@ -219,7 +269,7 @@ PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint
         if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
     } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
         if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) {
-            frac_start(g, tv.ray, tv.m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
+            frac_start(g, tv.pi, tv.ray, tv.m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
             return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
         }
     } else if (type != FIG_SKIP) {
@@ -496,7 +546,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             const DPrim& gw = slot_prim(sc, tv.slot);
             if (gw.type == FIG_MANDELBULB || gw.type == FIG_JULIA) {
                 park_u[PK_MISC * 64] = bounce | (attempt << 24);  // the planes may have moved bound / slot: those live in tv
-                frac_start(gw, tv.ray, tv.bound, FP_N0, tet_offset(0u, 0.5773f * PT_EPS * 2.0f), frac);
+                frac_start(gw, tv.slot, tv.ray, tv.bound, FP_N0, tet_offset(0u, 0.5773f * PT_EPS * 2.0f), frac);
                 return gw.type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
             }
         }
