@@ -240,9 +240,10 @@ PT_DEV void sched_body(const TraceParams& P) {
     // FRAC: which lanes of each wave stand in an estimator (republished every scheduling round), for the other waves'
     // idle lanes to take evaluations from (sched_dev.h, FS_*); every status word starts idle before any wave looks.
     __shared__ unsigned long long est_lanes[2][PTX_WAVES_PER_BLOCK];
+    __shared__ uint32_t est_serving[PTX_WAVES_PER_BLOCK];  // the estimator state a wave is serving right now (its own lanes are at their evaluations), or 0
     if (FRAC) {
         ((uint32_t*)frac)[FR_STATUS * 64] = FS_IDLE;
-        if (lane == 0u) { est_lanes[0][wave] = 0ull; est_lanes[1][wave] = 0ull; }
+        if (lane == 0u) { est_lanes[0][wave] = 0ull; est_lanes[1][wave] = 0ull; est_serving[wave] = 0u; }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __syncthreads();
     }
@@ -305,6 +306,7 @@ PT_DEV void sched_body(const TraceParams& P) {
             if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
         } else {
             const uint32_t n0 = pop[pick];
+            if (FRAC && lane == 0u) est_serving[wave] = pick;
             for (;;) {
                 PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(S == pick)));
                 PT_SITE_HIST(60, live);
@@ -324,6 +326,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                         uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                         for (uint32_t k = 1u; k < (uint32_t)PTX_WAVES_PER_BLOCK; k++) {
                             const uint32_t w2 = (wave + k) % (uint32_t)PTX_WAVES_PER_BLOCK;
+                            if (est_serving[w2] == pick) continue;  // that wave's lanes are at their own evaluations now
                             const unsigned long long m2 = est_lanes[pick - (uint32_t)LS_MANDEL][w2];
                             const uint32_t c2 = (uint32_t)__popcll(m2);
                             if (r < c2) {
@@ -342,6 +345,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
                 if (m == 0u || m * 4u < n0 * 3u) break;
             }
+            if (FRAC && lane == 0u) est_serving[wave] = 0u;
         }
     }
     const uint32_t n_bounce = px_u[7 * 64];
