@@ -90,6 +90,22 @@ int ptx_create(int device, ptx_ctx** out);
 void ptx_destroy(ptx_ctx* ctx);
 const char* ptx_last_error(const ptx_ctx* ctx);
 
+/* Explicit overrides of the choices the library makes per scene (no reference counterpart; for tests and
+ * measurement runs: every setting renders the same frames).  Takes effect at once for the uploaded scene, except
+ * upload_path, which the next ptx_upload_scene reads.  Keys and values:
+ *   kernel_family  -1 per scene (default), 0 lockstep kernels, 1 wave-scheduled kernels
+ *   upload_path    -1 by scene size, 0 record re-layout on the host, 1 on the device
+ *   claim_tile      0 per scene, 1 or 64 pixel jobs per claim
+ *   split_samples   1 (default) / 0: sample-granular jobs + fold for fractal scenes
+ *   split_chunk     0 = bounded by the staging buffer, else samples per chunk
+ *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes
+ *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with
+ *                  lanes at leaf primitives a state of their own, 2 walks to a leaf, tests wait as their own state
+ *   grid_per_cu     0 = every resident workgroup, else workgroups per compute unit
+ *   verbose, bvh_timing   0 / 1: notes on stderr
+ * PTX_ERR_BAD_ARG for an unknown key or a value outside its range. */
+int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value);
+
 /* Scene upload: replaces AppState::create_geometry_buffers and the two texture buffers
  * (src/app/state.rs:389-446, 179-182) and bind group 1 (state.rs:717-741, 833-883).  Counts are
  * explicit: pass the real lists, NOT the reference's one-element placeholder buffers

@@ -588,7 +588,19 @@ struct ptx_ctx {
     uint32_t share_leaf = 4u;           // and the share of lanes at leaf primitives (one-visit-per-step mode)
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
-    bool split = true;            // scheduled fractal kernels: sample-granular jobs + fold (PTX355_SPLIT=0 turns it off)
+    bool split = true;            // scheduled fractal kernels: sample-granular jobs + fold
+    uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
+    // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
+    struct Options {
+        int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
+        int upload = -1;          // upload_path: -1 by size, 0 re-layout on the host, 1 on the device
+        uint32_t claim_tile = 0;  // 0 per scene, 1 or 64
+        uint32_t split_chunk = 0; // 0 = as many samples per chunk as the staging bound allows
+        uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
+        int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
+        uint32_t grid_per_cu = 0; // 0 = every resident workgroup
+        bool verbose = false, bvh_timing = false;
+    } opt;
     float4* staging = nullptr;    // their staged samples, [sample][frame pixel]
     size_t staging_n = 0;
     const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
@@ -739,7 +751,8 @@ int relayout_on_device(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const p
     if (nmat) HIP_TRY(c, hipMemcpyAsync(d_mats, mats, (size_t)nmat * sizeof(ptx_material), hipMemcpyHostToDevice, st));
     if (nnode) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nnode * sizeof(ptx_bvh_node), hipMemcpyHostToDevice, st));
     if (nprim) HIP_TRY(c, hipMemcpyAsync(d_prims, prims, (size_t)nprim * 4, hipMemcpyHostToDevice, st));
-    const uint32_t res0[R_WORDS] = {0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    uint32_t res0[R_WORDS] = {0u};
+    res0[R_SKY_INDEX] = 0xFFFFFFFFu;
     HIP_TRY(c, hipMemcpyAsync(d_res, res0, sizeof(res0), hipMemcpyHostToDevice, st));
     auto blocks = [](uint32_t n) { return dim3((n + 255u) / 256u); };
     if (nfig) hipLaunchKernelGGL(shade_kernel, blocks(nfig), dim3(256), 0, st, (const ptx_shape*)d_figs, nfig, (const ptx_material*)d_mats, nmat, d_shade, d_res);
@@ -771,19 +784,18 @@ int relayout_on_device(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const p
         hipLaunchKernelGGL(depth_init_kernel, blocks(nnode), dim3(256), 0, st, d_depth, nnode);
         HIP_TRY(c, hipGetLastError());
         root_ref = nodes[0].prim_count > 0u ? (nodes[0].left_or_prim | (nodes[0].prim_count << PT_REF_BITS)) : 0u;  // the root's pair is record 0
-        // Longest chain of inner nodes from the root (bounds the stack occupancy): one level per pass.
-        if (nodes[0].prim_count == 0u)
-            for (uint32_t level = 0u;; level++) {
-                depth = level + 1u;
-                uint32_t changed = 0u;
-                HIP_TRY(c, hipMemsetAsync(d_res + R_CHANGED, 0, 4, st));
+        // Longest chain of inner nodes from the root (bounds the stack occupancy): one level per pass, every pass
+        // flags its level when it holds an inner node, one read-back at the end.  The traversal stack never holds more
+        // than 31 entries, so levels beyond R_LEVELS need not be told apart.
+        if (nodes[0].prim_count == 0u) {
+            for (uint32_t level = 0u; level < R_LEVELS; level++)
                 hipLaunchKernelGGL(depth_pass_kernel, blocks(nnode), dim3(256), 0, st, (const ptx_bvh_node*)d_nodes, nnode, d_depth, level, d_res);
-                HIP_TRY(c, hipGetLastError());
-                HIP_TRY(c, hipMemcpyAsync(&changed, d_res + R_CHANGED, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(c, hipStreamSynchronize(st));
-                if (!changed) break;
-                if (level > nnode) return fail(c, PTX_ERR_STATE, "BVH depth pass does not end");
-            }
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            for (uint32_t level = 0u; level < R_LEVELS; level++)
+                if (res[R_LEVEL0 + level]) depth = level + 1u;
+        }
     } else {
         HIP_TRY(c, scene_alloc((void**)&d_pairs, 0));
     }
@@ -834,15 +846,94 @@ void ptx_destroy(ptx_ctx* c) {
 
 const char* ptx_last_error(const ptx_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+static int configure(ptx_ctx* c);
+
+int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return PTX_ERR_BAD_ARG;
+    const std::string k(key);
+    auto in = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+    ptx_ctx::Options& o = c->opt;
+    bool ok = true;
+    if (k == "kernel_family") { if ((ok = in(-1, 1))) o.family = (int)value; }
+    else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
+    else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || value == 64)) o.claim_tile = (uint32_t)value; }
+    else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
+    else if (k == "split_chunk") { if ((ok = in(0, 0x7FFFFFFF))) o.split_chunk = (uint32_t)value; }
+    else if (k == "share_walk") { if ((ok = in(0, 64))) o.shares[0] = (uint32_t)value; }
+    else if (k == "share_post") { if ((ok = in(0, 64))) o.shares[1] = (uint32_t)value; }
+    else if (k == "share_march") { if ((ok = in(0, 64))) o.shares[2] = (uint32_t)value; }
+    else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
+    else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
+    else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
+    else if (k == "verbose") { o.verbose = value != 0; }
+    else if (k == "bvh_timing") { o.bvh_timing = value != 0; }
+    else return fail(c, PTX_ERR_BAD_ARG, "ptx_set_option: unknown key '" + k + "'");
+    if (!ok) return fail(c, PTX_ERR_BAD_ARG, "ptx_set_option: value " + std::to_string((long long)value) + " out of range for '" + k + "'");
+    if (c->have_scene) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        return configure(c);
+    }
+    return PTX_OK;
+}
+
 // Which kernel family runs a scene.  The wave-scheduled kernels win wherever lanes need very unequal numbers of
 // steps: trees read from global memory (meshes) and the long ray marchers (Moebius, Mandelbulb, Julia); small
-// closed-form scenes (the Cornell box, torus included) run faster in lockstep.  PTX355_SCHED=0/1 in the
-// environment overrides the rule (measurement runs).
+// closed-form scenes (the Cornell box, torus included) run faster in lockstep.  The kernel_family option
+// overrides the rule (tests, measurement runs).
 // type_mask: 1 << type over the BVH primitives that can be hit.
-static bool pick_sched(const DScene& sc, uint32_t type_mask) {
-    if (const char* e = getenv("PTX355_SCHED")) return e[0] == '1';
+static bool pick_sched(const DScene& sc, uint32_t type_mask, int forced) {
+    if (forced >= 0) return forced == 1;
     if (sc.lds_scene_bytes == 0u || sc.has_fractals != 0u) return true;
     return (type_mask & (1u << FIG_MEBIUS)) != 0u;
+}
+
+typedef void (*TraceKernel)(const TraceParams);
+static TraceKernel trace_kernel_of(const ptx_ctx* c) {
+    const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
+    return c->sched ? (lds ? (frac ? ptx_sched_kernel_lds_frac : ptx_sched_kernel_lds) : (frac ? ptx_sched_kernel_frac : ptx_sched_kernel))
+                    : (lds ? (frac ? ptx_trace_kernel_lds_frac : ptx_trace_kernel_lds) : (frac ? ptx_trace_kernel_frac : ptx_trace_kernel));
+}
+// Dynamic LDS of a trace workgroup for the uploaded scene: stack entries + per-lane fields (+ the staged scene, + the
+// estimator states of the scheduled fractal kernels).
+static size_t trace_lds_bytes(const ptx_ctx* c) {
+    const size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.lds_stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
+    return lds + c->sc.lds_scene_bytes + (c->sched && c->sc.has_fractals != 0u ? (size_t)PTX_WAVES_PER_BLOCK * 64u * SC_FRAC_FIELDS * 4u : 0u);
+}
+
+// Per-scene choices (kernel family, scheduling shares, claim size, resident workgroups per compute unit) from the
+// uploaded scene's class and the options; run at upload and whenever an option changes.
+static int configure(ptx_ctx* c) {
+    if (!c->have_scene) return PTX_OK;
+    const DScene& sc = c->sc;
+    const uint32_t type_mask = c->type_mask;
+    const uint32_t fractal_bits = (1u << FIG_MANDELBULB) | (1u << FIG_JULIA);
+    c->sched = pick_sched(sc, type_mask, c->opt.family);
+    const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {4u, 2u, 4u};
+    // deep trees (one node visit per step, lanes at leaf primitives served as a state of their own): walk, post, march, leaf
+    const uint32_t deep_mesh[4] = {12u, 2u, 4u, 4u}, deep_mixed[4] = {4u, 2u, 16u, 6u};
+    const bool marchers = (type_mask & ((1u << FIG_TORUS) | (1u << FIG_MEBIUS) | fractal_bits)) != 0u;
+    const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
+    c->share_leaf = 4u;
+    if (sc.stack_entries >= PT_DEEP_TREE) {
+        pick = marchers ? deep_mixed : deep_mesh;
+        c->share_leaf = pick[3];
+    }
+    memcpy(c->shares, pick, sizeof(c->shares));
+    for (int i = 0; i < 3; i++)
+        if (c->opt.shares[i]) c->shares[i] = c->opt.shares[i];
+    if (c->opt.shares[3]) c->share_leaf = c->opt.shares[3];
+    c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
+    if (c->opt.claim_tile) c->claim_tile = c->opt.claim_tile > 1u ? 64u : 1u;
+    // Resident workgroups per compute unit of the kernel this scene runs: the claiming kernels' grid.
+    const TraceKernel kernel = trace_kernel_of(c);
+    const size_t lds_all = trace_lds_bytes(c);
+    if (c->occ_kernel != (const void*)kernel || c->occ_lds != lds_all) {
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_per_cu, kernel, (int)PTX_BLOCK, lds_all));
+        c->occ_kernel = (const void*)kernel;
+        c->occ_lds = lds_all;
+        if (c->opt.verbose) fprintf(stderr, "ptx355: %s, %d workgroups per compute unit, %zu B LDS each\n", ptx_trace_kernel_name(c), c->occ_per_cu, lds_all);
+    }
+    return PTX_OK;
 }
 
 
@@ -859,9 +950,9 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     free_scene(c);
     if (nprim > PT_REF_MASK || nnode > PT_REF_MASK) return fail(c, PTX_ERR_UNSUPPORTED, "more than 2^29 nodes or primitives");
     // Where the re-layout runs: large scenes on the device (relayout.h), small ones on the host, whose loops cost
-    // less than the launches.  Both give the same records.  PTX355_UPLOAD=host|device overrides (tests, measurements).
+    // less than the launches.  Both give the same records.  The upload_path option overrides (tests, measurements).
     bool on_device = nfig >= 65536u || nprim >= 65536u;
-    if (const char* e = getenv("PTX355_UPLOAD")) on_device = e[0] == 'd';
+    if (c->opt.upload >= 0) on_device = c->opt.upload == 1;
 
     std::vector<DNeg> negs;
     int32_t sky_tex = -1;
@@ -1038,30 +1129,8 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     }
     c->sc = sc;
     c->have_scene = true;
-    c->sched = pick_sched(sc, type_mask);
-    {
-        const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {4u, 2u, 4u};
-        // deep trees (one node visit per step, lanes at leaf primitives served as a state of their own): walk, post, march, leaf
-        const uint32_t deep_mesh[4] = {12u, 2u, 4u, 4u}, deep_mixed[4] = {4u, 2u, 16u, 6u};
-        const bool marchers = (type_mask & ((1u << FIG_TORUS) | (1u << FIG_MEBIUS) | fractal_bits)) != 0u;
-        const uint32_t* pick = sc.lds_scene_bytes == 0u ? (marchers ? mixed : mesh) : (sc.has_fractals ? fractal : small);
-        c->share_leaf = 4u;
-        if (sc.stack_entries >= PT_DEEP_TREE) {
-            pick = marchers ? deep_mixed : deep_mesh;
-            c->share_leaf = pick[3];
-        }
-        memcpy(c->shares, pick, sizeof(c->shares));
-        c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
-        if (const char* e = getenv("PTX355_CLAIM_TILE")) c->claim_tile = atoi(e) > 1 ? 64u : 1u;
-        if (const char* e = getenv("PTX355_SPLIT")) c->split = e[0] != '0';
-        if (const char* e = getenv("PTX355_SHARES")) {  // measurement runs: "walk,post,march"
-            unsigned w = 0, p = 0, m = 0;
-            unsigned l = 0;
-            const int got = sscanf(e, "%u,%u,%u,%u", &w, &p, &m, &l);
-            if (got >= 3 && w && p && m) { c->shares[0] = w; c->shares[1] = p; c->shares[2] = m; }
-            if (got == 4 && l) c->share_leaf = l;
-        }
-    }
+    c->type_mask = type_mask;
+    if ((rc = configure(c))) { free_scene(c); return rc; }
     return PTX_OK;
 }
 
@@ -1071,14 +1140,21 @@ int ptx_resize(ptx_ctx* c, uint32_t w, uint32_t h) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_frame(c);
-    size_t n = (size_t)w * h;
-    HIP_TRY(c, hipMalloc((void**)&c->accum, n * 16));
-    HIP_TRY(c, hipMalloc((void**)&c->out, n * 4));
-    HIP_TRY(c, hipMalloc((void**)&c->ids, n * 4));
-    if (c->moments) HIP_TRY(c, hipMalloc((void**)&c->m2, n * 12));
+    c->w = 0; c->h = 0; c->tx0 = 0; c->ty0 = 0; c->tw = 0; c->th = 0;  // no frame until every buffer of the new one exists
+    const size_t n = (size_t)w * h;
+    hipError_t e = hipMalloc((void**)&c->accum, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->out, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->ids, n * 4);
+    if (e == hipSuccess && c->moments) e = hipMalloc((void**)&c->m2, n * 12);
+    if (e != hipSuccess) {
+        free_frame(c);
+        return fail(c, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("ptx_resize: hipMalloc: ") + hipGetErrorString(e));
+    }
     c->w = w; c->h = h;
     c->tx0 = 0; c->ty0 = 0; c->tw = w; c->th = h;
-    return ptx_clear(c);
+    const int rc = ptx_clear(c);
+    if (rc != PTX_OK) { free_frame(c); c->w = 0; c->h = 0; c->tw = 0; c->th = 0; }
+    return rc;
 }
 
 int ptx_set_tile(ptx_ctx* c, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
@@ -1113,7 +1189,7 @@ int ptx_clear(ptx_ctx* c) {
 int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n) {
     if (!c || !cam) return PTX_ERR_BAD_ARG;
     if (!c->have_scene) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_upload_scene");
-    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_resize");
+    if (!c->accum || !c->out || !c->ids) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_resize");
     if (cam->width != c->w || cam->height != c->h) return fail(c, PTX_ERR_BAD_ARG, "camera width/height differ from the frame size");
     if (n == 0) return PTX_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1133,47 +1209,37 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     P.m2 = c->moments ? c->m2 : nullptr;
     P.dbg_radiance = c->dbg; P.dbg_capacity = c->dbg_cap;
     P.stats = c->stats;
-    size_t lds = (size_t)PTX_WAVES_PER_BLOCK * 64u * (c->sc.lds_stack_entries * sizeof(StackEntry) + (PT_PIXEL_FIELDS + PT_PARK_FIELDS) * 4u);
     const bool frac = c->sc.has_fractals != 0u;
-    const size_t lds_all = lds + c->sc.lds_scene_bytes +  // lds_scene_bytes is 0 for the global-memory kernels
-                           (c->sched && frac ? (size_t)PTX_WAVES_PER_BLOCK * 64u * SC_FRAC_FIELDS * 4u : 0u);
-    void (*kernel)(const TraceParams) =
-        c->sched ? (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_sched_kernel_lds_frac : ptx_sched_kernel_lds) : (frac ? ptx_sched_kernel_frac : ptx_sched_kernel))
-                 : (c->sc.lds_scene_bytes > 0u ? (frac ? ptx_trace_kernel_lds_frac : ptx_trace_kernel_lds) : (frac ? ptx_trace_kernel_frac : ptx_trace_kernel));
+    const size_t lds_all = trace_lds_bytes(c);
+    const TraceKernel kernel = trace_kernel_of(c);
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
     const bool claim = c->sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u);
     uint32_t grid = P.n_blocks;
     if (claim) {
-        if (c->occ_kernel != (const void*)kernel || c->occ_lds != lds_all) {
-            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_per_cu, kernel, (int)PTX_BLOCK, lds_all));
-            c->occ_kernel = (const void*)kernel;
-            c->occ_lds = lds_all;
-            if (getenv("PTX355_VERBOSE")) fprintf(stderr, "ptx355: %d workgroups per compute unit, %zu B LDS each\n", c->occ_per_cu, lds_all);
-        }
-        int per_cu = c->occ_per_cu;
+        int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
         if (per_cu < 1) return fail(c, PTX_ERR_STATE, "the trace kernel does not fit a compute unit with this scene's LDS size");
-        if (const char* e = getenv("PTX355_GRID_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
+        if (c->opt.grid_per_cu >= 1u && (int)c->opt.grid_per_cu < per_cu) per_cu = (int)c->opt.grid_per_cu;
         const uint32_t resident = c->n_cu * (uint32_t)per_cu;
         grid = P.n_blocks < resident ? P.n_blocks : resident;
     }
-    { int rc = ensure_spill(c, (size_t)grid * PTX_WAVES_PER_BLOCK, &P.stack_spill); if (rc) return rc; }
+    const size_t waves = (size_t)grid * PTX_WAVES_PER_BLOCK;
+    { int rc = ensure_spill(c, waves, &P.stack_spill); if (rc) return rc; }
     if (claim) {
-        const size_t waves = (size_t)grid * PTX_WAVES_PER_BLOCK;
         if (waves > c->wave_tiles_n) {
             if (c->wave_tiles) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->wave_tiles); c->wave_tiles = nullptr; c->wave_tiles_n = 0; }
             HIP_TRY(c, hipMalloc((void**)&c->wave_tiles, waves * sizeof(uint2)));
             c->wave_tiles_n = waves;
         }
-        HIP_TRY(c, hipMemsetAsync(c->wave_tiles, 0, waves * sizeof(uint2), c->stream));
         P.wave_tiles = c->wave_tiles;
         P.job_counter = (uint32_t*)&c->stats[15];
+        if (c->claim_tile > 1u) HIP_TRY(c, hipMemsetAsync(P.wave_tiles, 0, waves * sizeof(uint2), c->stream));  // single-pixel claims never touch it
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
-        if (const char* e = getenv("PTX355_WALK_SINGLE")) P.walk_single = (uint32_t)(e[0] - '0') <= 2u ? (uint32_t)(e[0] - '0') : 0u;  // measurement and test runs
+        if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
         P.share_leaf = c->share_leaf;
     }
     // Fractal scenes: a pixel on a fractal's silhouette costs hundreds of times a background pixel, and with one
@@ -1186,7 +1252,7 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         const size_t frame_pixels = (size_t)c->w * c->h;
         size_t by_mem = ((size_t)4 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)P.n_blocks * 256u);
         size_t m = by_mem < by_jobs ? by_mem : by_jobs;
-        if (const char* e = getenv("PTX355_SPLIT_CHUNK")) { size_t v = (size_t)atoi(e); if (v >= 1 && v < m) m = v; }  // tests
+        if (c->opt.split_chunk >= 1u && c->opt.split_chunk < m) m = c->opt.split_chunk;
         if (m < 1) m = 1;
         if (m < chunk) chunk = (uint32_t)m;
         if (chunk * frame_pixels > c->staging_n) {
@@ -1341,8 +1407,8 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
     if (n > 0x3FFFFFFFu) return fail(c, PTX_ERR_BAD_ARG, "ptx_bvh_build: more than 2^30 primitives");
     HIP_TRY(c, hipSetDevice(c->device));
     using namespace bvhb;
-    // PTX355_BVH_TIMING=1: wall time of the phases on stderr (measurement runs)
-    const bool timing = getenv("PTX355_BVH_TIMING") != nullptr;
+    // the bvh_timing option: wall time of the phases on stderr (measurement runs)
+    const bool timing = c->opt.bvh_timing;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     const auto t_start = now();

@@ -17,8 +17,9 @@ enum : uint32_t {
     R_NEG_COUNT = 1,   // subtraction shapes among the figures
     R_SKY_INDEX = 2,   // lowest index of a textured skybox figure, or 0xFFFFFFFF
     R_TYPE_MASK = 3,   // 1 << type over the BVH primitives that can be hit
-    R_CHANGED = 4,     // depth pass: a node received its depth
-    R_WORDS = 8
+    R_LEVEL0 = 8,      // depth pass: word R_LEVEL0 + l is set when level l of the tree holds an inner node
+    R_LEVELS = 32,
+    R_WORDS = R_LEVEL0 + R_LEVELS
 };
 enum : uint32_t {
     E_MATERIAL = 1u,   // figure material_idx out of range
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) depth_pass_kernel(const ptx_bvh_node* nod
     if (i >= nnode || depth[i] != level || nodes[i].prim_count != 0u) return;
     depth[i + 1u] = level + 1u;
     depth[nodes[i].left_or_prim] = level + 1u;
-    if (nodes[i + 1u].prim_count == 0u || nodes[nodes[i].left_or_prim].prim_count == 0u) res[R_CHANGED] = 1u;
+    res[R_LEVEL0 + level] = 1u;  // every writer stores the same value
 }
 
 }  // namespace relay

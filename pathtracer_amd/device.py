@@ -85,6 +85,19 @@ class PathTracer:
         cam = _arr(cam, CAMERA_DT)
         self._ck(self.lib.ptx_trace_n(self.h, _p(cam), first_frame, first_sample, n), "ptx_trace_n")
 
+    def set_option(self, key: str, value: int):
+        self._ck(self.lib.ptx_set_option(self.h, key.encode(), int(value)), "ptx_set_option")
+
+    def set_options(self, **kv):
+        for k, v in kv.items():
+            self.set_option(k, v)
+
+    DEFAULT_OPTIONS = dict(kernel_family=-1, upload_path=-1, claim_tile=0, split_samples=1, split_chunk=0, share_walk=0, share_post=0,
+                           share_march=0, share_leaf=0, walk_mode=-1, grid_per_cu=0)
+
+    def reset_options(self):
+        self.set_options(**self.DEFAULT_OPTIONS)
+
     def sync(self):
         self._ck(self.lib.ptx_sync(self.h), "ptx_sync")
 

@@ -359,23 +359,26 @@ def test_deep_bvh_heightfield_matches_oracle(pt):
 
 
 @pytest.mark.parametrize("shares", ["12,2,4,4", "4,2,16,6", "64,2,4,1"])
-def test_deep_bvh_heightfield_in_single_visit_mode_matches_oracle(pt, shares, monkeypatch):
+def test_deep_bvh_heightfield_in_single_visit_mode_matches_oracle(pt, shares):
     """What trees of millions of primitives run (one node visit per WALK step, lanes at leaf primitives as a state of their
     own), forced on a tree the oracle finishes in seconds, with the shares of both deep scene classes and an extreme one."""
-    monkeypatch.setenv("PTX355_WALK_SINGLE", "1")
-    monkeypatch.setenv("PTX355_SHARES", shares)
+    sw, sp, sm, sl = (int(v) for v in shares.split(","))
+    pt.set_options(walk_mode=1, share_walk=sw, share_post=sp, share_march=sm, share_leaf=sl)
     sc = host.Scene.from_fixture(fixture("all"))
     sc.append_heightfield(48, glass_every=16)
     sc.build()
     b = sc.buffers()
     sb = hp.SceneBuffers(b["figs"], b["mats"], b["nodes"], b["prims"], b["lights"], b["infinite"], b["tex_pixels"], b["tex_infos"],
                          hp.scene_from_fixture(fixture("all"))[1])
-    _compare(pt, sb, 128, 72, 3)
-    assert "sched" in pt.kernel_name()
+    try:
+        _compare(pt, sb, 128, 72, 3)
+        assert "sched" in pt.kernel_name()
+    finally:
+        pt.reset_options()
 
 
 @pytest.mark.parametrize("name,quads", [("cornell_box", 0), ("teapot", 0), ("fractals", 0), ("all", 0), ("planet", 0), ("all", 40)])
-def test_scene_relayout_on_the_device_equals_the_host_relayout(pt, name, quads, monkeypatch):
+def test_scene_relayout_on_the_device_equals_the_host_relayout(pt, name, quads):
     """ptx_upload_scene builds the kernels' records on the host for small scenes and on the device for large ones:
     forced either way, the same kernel is picked and frames, ids, M2 and counters are identical."""
     sc = host.Scene.from_fixture(fixture(name))
@@ -386,7 +389,7 @@ def test_scene_relayout_on_the_device_equals_the_host_relayout(pt, name, quads, 
     cam = sc.camera(w, h)
     got = {}
     for where in ("host", "device"):
-        monkeypatch.setenv("PTX355_UPLOAD", where)
+        pt.set_option("upload_path", 1 if where == "device" else 0)
         sc.upload_to(pt)
         pt.enable_moments(True)
         pt.resize(w, h)
@@ -395,14 +398,15 @@ def test_scene_relayout_on_the_device_equals_the_host_relayout(pt, name, quads, 
         got[where] = (pt.kernel_name(), pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
                       (st["paths"], st["bounces"], st["shadow_rays"]))
         pt.enable_moments(False)
+    pt.reset_options()
     a, b = got["host"], got["device"]
     assert a[0] == b[0] and a[5] == b[5]
     assert same_bits(a[1], b[1]) == 0 and same_bits(a[2], b[2]) == 0 and (a[3] == b[3]).all() and (a[4] == b[4]).all()
 
 
-def test_error_reporting_of_the_device_relayout(monkeypatch):
-    monkeypatch.setenv("PTX355_UPLOAD", "device")
+def test_error_reporting_of_the_device_relayout():
     fresh = PathTracer(0)
+    fresh.set_option("upload_path", 1)
     sb = hp.prepare_fixture(fixture("teapot"))
     bad = sb.prims.copy()
     bad[5] = len(sb.figs)
@@ -458,7 +462,7 @@ def test_error_reporting(pt):
 
 
 @pytest.mark.parametrize("name,w,h,n", [("cornell_box", 160, 90, 5), ("teapot", 200, 112, 3), ("fractals", 64, 36, 3), ("all", 128, 72, 3)])
-def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w, h, n, monkeypatch):
+def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w, h, n):
     """The lockstep and the wave-scheduled kernels, with single-pixel and 64-pixel claims, are interchangeable:
     same accumulation, M2, ids, rgba8 and counters on every scene (the host picks per scene; here each is forced)."""
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
@@ -469,16 +473,11 @@ def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w,
     # with leaf shares that serve them early ("64") and late ("2")
     for sched, tile, split, single in (("0", "1", "0", ""), ("1", "1", "0", ""), ("1", "1", "1", ""), ("1", "1", "2", ""), ("1", "64", "0", ""),
                                        ("0", "64", "0", ""), ("1", "1", "0", "64"), ("1", "64", "1", "2"), ("1", "64", "0", "5")):
-        monkeypatch.setenv("PTX355_SCHED", sched)
-        monkeypatch.setenv("PTX355_CLAIM_TILE", tile)
-        monkeypatch.setenv("PTX355_SPLIT", "0" if split == "0" else "1")
-        monkeypatch.setenv("PTX355_SPLIT_CHUNK", "2" if split == "2" else "1000")
+        pt.reset_options()
+        pt.set_options(kernel_family=int(sched), claim_tile=int(tile), split_samples=0 if split == "0" else 1,
+                       split_chunk=2 if split == "2" else 1000)
         if single:
-            monkeypatch.setenv("PTX355_WALK_SINGLE", "1")
-            monkeypatch.setenv("PTX355_SHARES", f"4,2,4,{single}")
-        else:
-            monkeypatch.delenv("PTX355_WALK_SINGLE", raising=False)
-            monkeypatch.delenv("PTX355_SHARES", raising=False)
+            pt.set_options(walk_mode=1, share_walk=4, share_post=2, share_march=4, share_leaf=int(single))
         sc.upload_to(pt)  # the family is chosen at upload
         assert ("sched" in pt.kernel_name()) == (sched == "1")
         pt.enable_moments(True)
@@ -488,8 +487,7 @@ def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w,
         results[(sched, tile, split, single)] = (pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(),
                                                  (st["paths"], st["bounces"], st["shadow_rays"]))
         pt.enable_moments(False)
-    for k in ("PTX355_SCHED", "PTX355_CLAIM_TILE", "PTX355_SPLIT", "PTX355_SPLIT_CHUNK", "PTX355_WALK_SINGLE", "PTX355_SHARES"):
-        monkeypatch.delenv(k, raising=False)
+    pt.reset_options()
     ref = results[("0", "1", "0", "")]
     for key, r in results.items():
         assert same_bits(r[0], ref[0]) == 0 and same_bits(r[1], ref[1]) == 0, key

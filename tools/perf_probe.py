@@ -17,6 +17,10 @@ if len(sys.argv) > 1:
 if os.environ.get("PROBE_N"):  # samples per launch, e.g. PROBE_N=2,8
     CASES = [(c[0], c[1], c[2], tuple(int(x) for x in os.environ["PROBE_N"].split(","))) for c in CASES]
 pt = PathTracer(0)
+# PROBE_OPTS="key=value,key=value": ptx_set_option settings for A/B runs (the library itself reads no environment)
+for kv in filter(None, os.environ.get("PROBE_OPTS", "").split(",")):
+    k, v = kv.split("=")
+    pt.set_option(k, int(v))
 for name, w, h, ns in CASES:
     sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
     cam = sc.camera(w, h)

@@ -20,7 +20,8 @@ w, h = 1920, 1080
 cam = sc.camera(w, h)
 first = None
 for s in settings:
-    os.environ["PTX355_SHARES"] = s
+    for key, v in zip(("share_walk", "share_post", "share_march", "share_leaf"), s.split(",")):
+        pt.set_option(key, int(v))
     sc.upload_to(pt)
     pt.resize(w, h)
     pt.trace_n(cam, 0, 1, 1)
