@@ -153,6 +153,18 @@ int ptx_trace(ptx_ctx* ctx, const ptx_camera* cam);
  * The output image is tone-mapped from the final mean, i.e. it equals the last frame's. */
 int ptx_trace_n(ptx_ctx* ctx, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n);
 
+/* ptx_trace_n for callers that cannot allocate device memory (code under HIP graph capture, serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same frames, bit for bit; the call
+ * itself allocates nothing and creates no events: the launch's scratch (pixel-claim counter, per-wave claim state,
+ * traversal-stack entries beyond the LDS part) lives in one array of 56.7 MB (PTX_STATIC_BYTES in the source) that
+ * every GPU the library runs on holds from load to exit, sized for 4096 waves: what a 256-CU device keeps resident;
+ * a larger claiming grid is cut down to that, a launch whose grid follows the frame size (kernel_family 0 on a mesh
+ * scene) and runs more waves fails with PTX_ERR_UNSUPPORTED.  Fractal scenes run whole-pixel jobs here (no staging buffer),
+ * which is slower than ptx_trace_n; ptx_kernel_time does not see these launches.  All calls on one GPU share the
+ * array: two of them in flight at once on one GPU (two contexts, two streams) race.  Scene upload, ptx_resize and
+ * the options are set up beforehand with the ordinary calls. */
+int ptx_trace_n_static(ptx_ctx* ctx, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n);
+
 int ptx_sync(ptx_ctx* ctx);
 
 /* Read-back: replaces copy_texture_to_buffer + map_async (src/app/rendering.rs:314-386).

@@ -27,6 +27,7 @@ SYMBOLS = [
     ("ptx_clear", C.c_int, [_P]),
     ("ptx_trace", C.c_int, [_P, _P]),
     ("ptx_trace_n", C.c_int, [_P, _P, _U, _U, _U]),
+    ("ptx_trace_n_static", C.c_int, [_P, _P, _U, _U, _U]),
     ("ptx_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("ptx_sync", C.c_int, [_P]),
     ("ptx_read_accum", C.c_int, [_P, _P]),

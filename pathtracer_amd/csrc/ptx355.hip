@@ -35,6 +35,16 @@
 #define PTX_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
 
+// Scratch of ptx_trace_n_static, the entry point that allocates nothing: the launch-wide pixel-claim counter, the
+// per-wave claim state and the deep traversal-stack entries of up to PTX_STATIC_MAX_WAVES waves (a 256-CU device
+// runs at most 4 workgroups of 4 waves per compute unit with these kernels' LDS use).  One copy per device, held
+// from module load to process exit; every call on a device shares it.
+#define PTX_STATIC_MAX_WAVES 4096u
+#define PTX_STATIC_TILES_OFFSET 256u
+#define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_TILES_OFFSET + PTX_STATIC_MAX_WAVES * 8u)
+#define PTX_STATIC_BYTES (PTX_STATIC_SPILL_OFFSET + (size_t)PTX_STATIC_MAX_WAVES * (31u - PT_LDS_STACK) * 64u * 8u)
+static __device__ __align__(256) unsigned char ptx_static_scratch[PTX_STATIC_BYTES];
+
 
 // Bijective block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so give the
 // blocks of one XCD a contiguous range of logical tile indices.
@@ -610,6 +620,7 @@ struct ptx_ctx {
     size_t wave_tiles_n = 0;
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
     size_t spill_waves = 0;
+    unsigned char* static_scratch = nullptr;  // this device's copy of ptx_static_scratch (its address, not the host-side symbol)
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     std::vector<hipEvent_t> free_events;
@@ -825,6 +836,13 @@ int ptx_create(int device, ptx_ctx** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     c->n_cu = (uint32_t)cus;
+    // Every device holds its own copy of the static scratch array at its own address: ask for it with this device current.
+    void* scratch_ptr = nullptr;
+    if (hipGetSymbolAddress(&scratch_ptr, HIP_SYMBOL(ptx_static_scratch)) != hipSuccess || !scratch_ptr) {
+        ptx_destroy(c);
+        return PTX_ERR_HIP;
+    }
+    c->static_scratch = (unsigned char*)scratch_ptr;
     *out = c;
     return PTX_OK;
 }
@@ -1186,7 +1204,10 @@ int ptx_clear(ptx_ctx* c) {
     return PTX_OK;
 }
 
-int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n) {
+// ptx_trace_n and ptx_trace_n_static.  `fixed`: the launch's scratch (pixel-claim counter, per-wave claim state, deep
+// stack entries) is the file-scope array ptx_static_scratch instead of buffers the context allocates and grows, no
+// events are created, and fractal scenes run whole-pixel jobs (no staging buffer): nothing is allocated.
+static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n, bool fixed) {
     if (!c || !cam) return PTX_ERR_BAD_ARG;
     if (!c->have_scene) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_upload_scene");
     if (!c->accum || !c->out || !c->ids) return fail(c, PTX_ERR_STATE, "ptx_trace before ptx_resize");
@@ -1223,17 +1244,32 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         if (c->opt.grid_per_cu >= 1u && (int)c->opt.grid_per_cu < per_cu) per_cu = (int)c->opt.grid_per_cu;
         const uint32_t resident = c->n_cu * (uint32_t)per_cu;
         grid = P.n_blocks < resident ? P.n_blocks : resident;
+        if (fixed && grid > PTX_STATIC_MAX_WAVES / PTX_WAVES_PER_BLOCK) grid = PTX_STATIC_MAX_WAVES / PTX_WAVES_PER_BLOCK;  // fewer workgroups claim the same jobs
     }
     const size_t waves = (size_t)grid * PTX_WAVES_PER_BLOCK;
-    { int rc = ensure_spill(c, waves, &P.stack_spill); if (rc) return rc; }
+    if (fixed) {
+        if (!c->static_scratch) return fail(c, PTX_ERR_STATE, "ptx_trace_n_static: the static scratch array has no address on this device");
+        if (waves > PTX_STATIC_MAX_WAVES)
+            return fail(c, PTX_ERR_UNSUPPORTED, "ptx_trace_n_static: this launch runs " + std::to_string(waves) + " waves, the static scratch array holds the state of " +
+                                                    std::to_string(PTX_STATIC_MAX_WAVES) + " (use ptx_trace_n)");
+        if (c->sc.lds_scene_bytes == 0u && c->sc.stack_entries > PT_LDS_STACK) P.stack_spill = (StackEntry*)(c->static_scratch + PTX_STATIC_SPILL_OFFSET);
+    } else {
+        int rc = ensure_spill(c, waves, &P.stack_spill);
+        if (rc) return rc;
+    }
     if (claim) {
-        if (waves > c->wave_tiles_n) {
-            if (c->wave_tiles) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->wave_tiles); c->wave_tiles = nullptr; c->wave_tiles_n = 0; }
-            HIP_TRY(c, hipMalloc((void**)&c->wave_tiles, waves * sizeof(uint2)));
-            c->wave_tiles_n = waves;
+        if (fixed) {
+            P.wave_tiles = (uint2*)(c->static_scratch + PTX_STATIC_TILES_OFFSET);
+            P.job_counter = (uint32_t*)c->static_scratch;
+        } else {
+            if (waves > c->wave_tiles_n) {
+                if (c->wave_tiles) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->wave_tiles); c->wave_tiles = nullptr; c->wave_tiles_n = 0; }
+                HIP_TRY(c, hipMalloc((void**)&c->wave_tiles, waves * sizeof(uint2)));
+                c->wave_tiles_n = waves;
+            }
+            P.wave_tiles = c->wave_tiles;
+            P.job_counter = (uint32_t*)&c->stats[15];
         }
-        P.wave_tiles = c->wave_tiles;
-        P.job_counter = (uint32_t*)&c->stats[15];
         if (c->claim_tile > 1u) HIP_TRY(c, hipMemsetAsync(P.wave_tiles, 0, waves * sizeof(uint2), c->stream));  // single-pixel claims never touch it
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
@@ -1246,7 +1282,7 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
     // lane folding all n samples of its pixel the launch ends on a few lanes finishing theirs.  There the jobs
     // are single samples, staged and folded in order by ptx_fold_kernel, in chunks that bound the staging buffer
     // (4 GiB of the 288: 128 samples of a 1080p frame; the launch's fixed cost, its last waves draining, is paid per chunk) and the job count.  Radiance capture keeps whole-pixel jobs (its sample index is launch-relative).
-    const bool split = c->sched && frac && c->split && n > 1u && !c->dbg;
+    const bool split = !fixed && c->sched && frac && c->split && n > 1u && !c->dbg;
     uint32_t chunk = n;
     if (split) {
         const size_t frame_pixels = (size_t)c->w * c->h;
@@ -1263,11 +1299,13 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
         P.staging = c->staging;
         P.frame_pixels = (uint32_t)frame_pixels;
     }
-    if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
-    hipEvent_t e0, e1;
-    int rc;
-    if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!fixed) {
+        if (c->pending.size() >= 256) { int rc = collect_timing(c); if (rc) return rc; }
+        int rc;
+        if ((rc = get_event(c, &e0)) || (rc = get_event(c, &e1))) return rc;
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
     for (uint32_t done = 0; done < n; done += chunk) {
         const uint32_t m = n - done < chunk ? n - done : chunk;
         P.first_frame = first_frame + done; P.first_sample = first_sample + done; P.n = m;
@@ -1283,9 +1321,19 @@ int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_
             HIP_TRY(c, hipGetLastError());
         }
     }
-    HIP_TRY(c, hipEventRecord(e1, c->stream));
-    c->pending.push_back({e0, e1});
+    if (!fixed) {
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        c->pending.push_back({e0, e1});
+    }
     return PTX_OK;
+}
+
+int ptx_trace_n(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n) {
+    return launch_trace(c, cam, first_frame, first_sample, n, false);
+}
+
+int ptx_trace_n_static(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame, uint32_t first_sample, uint32_t n) {
+    return launch_trace(c, cam, first_frame, first_sample, n, true);
 }
 
 int ptx_trace(ptx_ctx* c, const ptx_camera* cam) {

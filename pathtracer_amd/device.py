@@ -85,6 +85,11 @@ class PathTracer:
         cam = _arr(cam, CAMERA_DT)
         self._ck(self.lib.ptx_trace_n(self.h, _p(cam), first_frame, first_sample, n), "ptx_trace_n")
 
+    def trace_n_static(self, cam: np.ndarray, first_frame: int, first_sample: int, n: int):
+        """ptx_trace_n_static: the same frames as trace_n from a call that allocates nothing."""
+        cam = _arr(cam, CAMERA_DT)
+        self._ck(self.lib.ptx_trace_n_static(self.h, _p(cam), first_frame, first_sample, n), "ptx_trace_n_static")
+
     def set_option(self, key: str, value: int):
         self._ck(self.lib.ptx_set_option(self.h, key.encode(), int(value)), "ptx_set_option")
 
