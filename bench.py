@@ -38,7 +38,7 @@ def cpu_baseline(scene, cam, label: str, spp: int, tile=None):
     from oracle import host_prep as hp, oracle as orc
     b = scene.buffers()
     sb = hp.SceneBuffers(b["figs"], b["mats"], b["nodes"], b["prims"], b["lights"], b["infinite"], b["tex_pixels"], b["tex_infos"], None)
-    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    threads = host_threads()
     osc = orc.OracleScene(sb)
     t0 = time.perf_counter()
     r = orc.render(osc, cam, spp, counters=True, threads=threads, tile=tile)
@@ -47,7 +47,41 @@ def cpu_baseline(scene, cam, label: str, spp: int, tile=None):
     where = "whole frame" if tile is None else f"tile x0={tile[0]} y0={tile[1]} {tile[2]}x{tile[3]}"
     return {"value": round(c["paths"] / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
             "sample": f"{label}: {where}, frames 0..{spp - 1} ({c['paths']} paths, {dt:.1f} s wall)",
-            "gpath_bounce_per_s": round(c["bounces"] / dt / 1e9, 6)}, c, orc.counted_flops(c)
+            "cores_note": f"{threads} OpenMP threads = every core this process may use ({host_threads.why})",
+            "gpath_bounce_per_s": round(c["bounces"] / dt / 1e9, 6)}, c, orc.counted_flops(c), r
+
+
+def host_threads() -> int:
+    """Every host core this process is given: its affinity mask, or the job's CPU share when the launcher states one
+    in OMP_NUM_THREADS (a one-GPU slice of a many-GPU host is allotted 16 of the machine's cores that way)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and 0 < int(share) < aff:
+        host_threads.why = f"OMP_NUM_THREADS={share} set by the launcher; affinity mask has {aff}"
+        return int(share)
+    host_threads.why = f"affinity mask has {aff}"
+    return max(1, aff)
+
+
+def image_rmse(pt, cam, spp: int, ref: dict, tile=None):
+    """The metric's 'image RMSE vs ref': the GPU's frames 0..spp-1 of this workload against the oracle's render of the
+    same frames (the one timed for cpu_baseline), outside the timed region.  Relative RMSE of the linear mean weighted
+    by luminance, RMSE of the rgba8 image in LSB, and the number of f32 words / primary ids that differ at all."""
+    pt.clear()
+    pt.trace_n(cam, 0, 1, spp)
+    a, out, ids = pt.read_accum(), pt.read_output(), pt.read_primary_ids()
+    W, H = int(cam[0]["width"]), int(cam[0]["height"])
+    x0, y0, tw, th = tile if tile is not None else (0, 0, W, H)
+    sl = (slice(y0, y0 + th), slice(x0, x0 + tw))
+    g, r = a[sl][..., :3].astype(np.float64), ref["accum"][sl][..., :3].astype(np.float64)
+    lw = np.array([0.2126, 0.7152, 0.0722])
+    lum_err = ((g - r) @ lw) ** 2
+    mean_lum = float((r @ lw).mean())
+    d8 = out[sl].astype(np.float64) - ref["rgba8"][sl].astype(np.float64)
+    return {"linear_rel_rmse": float(np.sqrt(lum_err.mean()) / max(mean_lum, 1e-30)), "rgba8_rmse_lsb": float(np.sqrt((d8 ** 2).mean())),
+            "f32_words_differing": int((a[sl].view(np.uint32) != ref["accum"][sl].view(np.uint32)).sum()),
+            "primary_ids_differing": int((ids[sl] != ref["primary_id"][sl]).sum()),
+            "frames": spp, "pixels": int(tw * th)}
 
 
 def main():
@@ -146,6 +180,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = pt.kernel_time()
+    per_launch = pt.kernel_times()[-args.steps:]
     st = pt.stats()
     total_paths = w * h * spp * args.steps * (1 if tiles else world)  # tiles: the ranks share one frame
     bounces = st["bounces"]
@@ -168,14 +203,17 @@ def main():
                        "scene_build_s": round(build_s, 3), "bvh_builder": "gpu" if gpu_bvh else "host", "scene_upload_s": round(upload_s, 3)},
             "gpath_bounce_per_s": round(total_bounces / elapsed / 1e9, 4),
             "bounces_per_path": round(bounces / max(st["paths"], 1), 4),
-            "image_rmse_vs_ref": 0.0,  # tests/test_gpu_*: bit-exact against the oracle at equal seeds
+            "ms_per_step_median": round(float(np.median(per_launch)), 3) if len(per_launch) else None,  # HIP events, per trace call
+            "image_rmse_vs_ref": None,
         }
         cpu, flops_per_bounce = None, None
-        if not args.no_cpu_baseline:
-            # bounded CPU samples: whole frames, 10-30 s of work on 16 cores
+        if not args.no_cpu_baseline and world == 1:
+            # bounded CPU samples: whole frames, 10-30 s of work on the box's host cores
             cpu_spp, cpu_tile = {"cornell": (64, None), "teapot": (24, None), "fractals": (8, None), "all_mesh": (4, None)}[args.workload]
-            cpu, cnt, flops = cpu_baseline(scene, cam, label, cpu_spp, cpu_tile)
+            cpu, cnt, flops, ref = cpu_baseline(scene, cam, label, cpu_spp, cpu_tile)
             flops_per_bounce = flops / max(cnt["bounces"], 1)
+            # the oracle's frames double as the reference image of the metric's RMSE (after the timed region; uses the tracer)
+            out["image_rmse_vs_ref"] = image_rmse(pt, cam, cpu_spp, ref, cpu_tile)
         avg_ms = kernel_ms / max(launches, 1)
         roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": pt.kernel_name(),
                 "kernel_avg_ms": round(avg_ms, 3), "launches": launches, "traffic": None}

@@ -236,6 +236,9 @@ const char* ptx_trace_kernel_name(const ptx_ctx* ctx);
 /* Sum of the trace kernels' durations (HIP events on the context's stream) and their count since the
  * last call; synchronises. */
 int ptx_kernel_time(ptx_ctx* ctx, float* total_ms, uint32_t* launches);
+/* The same durations one by one, in call order, since the last call of this function (at most 65 536 are kept):
+ * up to `capacity` of them go to ms_out, *count receives how many there were; synchronises. */
+int ptx_kernel_times(ptx_ctx* ctx, float* ms_out, uint32_t capacity, uint32_t* count);
 
 /* Unit hooks for known-answer tests, evaluated on the device.
  * ptx_kat_math: op 0 sin, 1 cos, 2 asin, 3 acos, 4 log, 5 log2, 6 exp2, 7 atan2(a,b), 8 pow(a,b),

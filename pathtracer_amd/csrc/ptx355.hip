@@ -626,6 +626,7 @@ struct ptx_ctx {
     std::vector<hipEvent_t> free_events;
     double acc_ms = 0.0;
     uint32_t acc_launches = 0;
+    std::vector<float> launch_ms;  // duration of every trace call since the last ptx_kernel_times
 };
 
 namespace {
@@ -695,6 +696,7 @@ int collect_timing(ptx_ctx* c) {
         HIP_TRY(c, hipEventElapsedTime(&ms, pr.first, pr.second));
         c->acc_ms += ms;
         c->acc_launches += 1;
+        if (c->launch_ms.size() < 65536u) c->launch_ms.push_back(ms);
         c->free_events.push_back(pr.first);
         c->free_events.push_back(pr.second);
     }
@@ -1621,6 +1623,18 @@ int ptx_kernel_time(ptx_ctx* c, float* total_ms, uint32_t* launches) {
     if (launches) *launches = c->acc_launches;
     c->acc_ms = 0.0;
     c->acc_launches = 0;
+    return PTX_OK;
+}
+
+int ptx_kernel_times(ptx_ctx* c, float* ms_out, uint32_t capacity, uint32_t* count) {
+    if (!c || !count || (capacity && !ms_out)) return PTX_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = collect_timing(c);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)c->launch_ms.size();
+    for (uint32_t i = 0; i < n && i < capacity; i++) ms_out[i] = c->launch_ms[i];
+    *count = n;
+    c->launch_ms.clear();
     return PTX_OK;
 }
 

@@ -191,6 +191,12 @@ class PathTracer:
         self._ck(self.lib.ptx_kernel_time(self.h, C.byref(ms), C.byref(n)), "ptx_kernel_time")
         return float(ms.value), int(n.value)
 
+    def kernel_times(self) -> np.ndarray:
+        """Durations (ms) of the trace calls since the last kernel_times(), one by one."""
+        buf, n = np.zeros(65536, dtype=np.float32), C.c_uint32()
+        self._ck(self.lib.ptx_kernel_times(self.h, _p(buf), buf.size, C.byref(n)), "ptx_kernel_times")
+        return buf[: min(n.value, buf.size)].copy()
+
     KAT_OPS = {"sin": 0, "cos": 1, "asin": 2, "acos": 3, "log": 4, "log2": 5, "exp2": 6, "atan2": 7, "pow": 8,
                "min": 9, "max": 10, "sqrt": 11, "div": 12, "fma_aba": 13, "rcp": 14}
 
