@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--partition", default="", choices=["", "samples", "tiles"],
                     help="N > 1: sample split (weak scaling, default) or interleaved 16x16 tiles (strong scaling, default for teapot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
+                    help="N > 1: the multi-GPU epilogue by the library's own RCCL exchange (ptx_merge_sample_split / ptx_assemble_tiles, default) "
+                         "or by the same steps over torch.distributed collectives")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,10 +142,20 @@ def main():
     tiles = world > 1 and partition == "tiles"
     if world > 1 and not tiles:
         pt.enable_moments(True)
+    if world > 1 and args.exchange == "library":
+        multigpu.setup_comm(pt, dist)  # the context's own RCCL communicator; the process group only carries its id
     pt.resize(w, h)
     if tiles:
         pt.set_partition(rank, world)  # this rank's interleaved 16x16 blocks; every rank traces the same frames
     cam = scene.camera(w, h)
+
+    def epilogue(samples_per_rank):
+        if args.exchange == "library":
+            (pt.assemble_tiles(cam) if tiles else pt.merge_sample_split([samples_per_rank] * world, cam))
+        elif tiles:
+            multigpu.assemble_tiles(pt, dist, device, cam)
+        else:
+            multigpu.merge_sample_split(pt, dist, device, [samples_per_rank] * world, cam)
 
     def barrier():
         pt.sync()
@@ -157,10 +170,7 @@ def main():
         pt.trace_n(cam, frame0 + i * spp, 1 + i * spp, spp)
     if dist is not None and args.warmup > 0:
         # the first collectives set up RCCL's channels: keep that out of the timed region
-        if tiles:
-            multigpu.assemble_tiles(pt, dist, device, cam)
-        else:
-            multigpu.merge_sample_split(pt, dist, device, [args.warmup * spp] * world, cam)
+        epilogue(args.warmup * spp)
     pt.sync()
     pt.clear()
     pt.kernel_time()
@@ -169,10 +179,7 @@ def main():
     for i in range(args.steps):
         pt.trace_n(cam, frame0 + (args.warmup + i) * spp, 1 + i * spp, spp)
     if dist is not None:
-        if tiles:
-            multigpu.assemble_tiles(pt, dist, device, cam)
-        else:
-            multigpu.merge_sample_split(pt, dist, device, [args.steps * spp] * world, cam)
+        epilogue(args.steps * spp)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -200,6 +207,7 @@ def main():
             "config": {"workload": label, "width": w, "height": h, "spp_per_step": spp, "frames": args.steps * spp,
                        "partition": "single GPU" if world == 1 else (f"interleaved 16x16 tiles over {world} GPUs + RCCL sum" if tiles
                                                                        else f"sample split over {world} GPUs + RCCL Chan merge"),
+                       "exchange": None if world == 1 else args.exchange,
                        "scene_build_s": round(build_s, 3), "bvh_builder": "gpu" if gpu_bvh else "host", "scene_upload_s": round(upload_s, 3)},
             "gpath_bounce_per_s": round(total_bounces / elapsed / 1e9, 4),
             "bounces_per_path": round(bounces / max(st["paths"], 1), 4),

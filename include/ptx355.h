@@ -214,6 +214,29 @@ void* ptx_device_moments(ptx_ctx* ctx);
 int ptx_merge_moments(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, uint32_t n_a,
                       const void* other_mean4, const void* other_m2, uint32_t n_b, const ptx_camera* cam);
 
+/* The multi-GPU exchange inside the boundary, over RCCL (no reference counterpart: the reference runs on one GPU).
+ * One process (or thread + context) per GPU.  The library loads RCCL at run time on the first of these calls and
+ * reuses a copy the process has already loaded; PTX_ERR_UNSUPPORTED when there is none.
+ *   ptx_comm_unique_id: 128 opaque bytes (an ncclUniqueId) made by ONE rank; the host carries them to the others
+ *     by whatever channel it has (a file, MPI, a torch.distributed broadcast).
+ *   ptx_comm_init: every rank, with the same bytes: creates this context's communicator (collective: returns when all
+ *     `world` ranks have called).  ptx_comm_adopt: uses an ncclComm_t the host already has (not destroyed with the
+ *     context); NULL detaches.  ptx_comm_free: destroys / detaches now instead of at ptx_destroy.
+ *   ptx_merge_sample_split: the epilogue of a sample split.  Every rank has traced the full frame for its own frame
+ *     indices with ptx_enable_moments on and first_sample = 1; counts[r] = samples rank r holds.  Slice j of every
+ *     rank's (mean, M2) goes to rank j (all peer links at once), rank j folds them with Chan's update in rank order
+ *     0, 1, 2, ... (the arithmetic of ptx_merge_moments: deterministic, equal to the sequential mean to rounding,
+ *     <= 1e-5 relative), and the merged slices go back to every rank; then the rgba8 image of the whole frame is
+ *     re-derived.  On return (asynchronous on the context's stream) every rank holds the merged mean, M2 and image.
+ *   ptx_assemble_tiles: the epilogue of a tile partition (ptx_set_partition): one SUM all-reduce of the disjoint
+ *     accumulation buffers (exact: untouched pixels are zero), then the rgba8 image of the whole frame. */
+int ptx_comm_unique_id(void* id128);
+int ptx_comm_init(ptx_ctx* ctx, const void* id128, uint32_t rank, uint32_t world);
+int ptx_comm_adopt(ptx_ctx* ctx, void* nccl_comm);
+int ptx_comm_free(ptx_ctx* ctx);
+int ptx_merge_sample_split(ptx_ctx* ctx, const uint32_t* counts, const ptx_camera* cam);
+int ptx_assemble_tiles(ptx_ctx* ctx, const ptx_camera* cam);
+
 /* Re-derives the rgba8 output of pixels [first_pixel, first_pixel + n_pixels) from the accumulation buffer
  * (apply_tonemap + rgba8unorm store, tonemap.wgsl:27-42, path_trace.wgsl:52-53): for accumulation data
  * that arrived from another GPU. */

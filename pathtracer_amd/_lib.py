@@ -43,6 +43,12 @@ SYMBOLS = [
     ("ptx_device_moments", _P, [_P]),
     ("ptx_merge_moments", C.c_int, [_P, _U, _U, _U, _P, _P, _U, _P]),
     ("ptx_tonemap", C.c_int, [_P, _U, _U, _P]),
+    ("ptx_comm_unique_id", C.c_int, [_P]),
+    ("ptx_comm_init", C.c_int, [_P, _P, _U, _U]),
+    ("ptx_comm_adopt", C.c_int, [_P, _P]),
+    ("ptx_comm_free", C.c_int, [_P]),
+    ("ptx_merge_sample_split", C.c_int, [_P, _P, _P]),
+    ("ptx_assemble_tiles", C.c_int, [_P, _P]),
     ("ptx_post_process", C.c_int, [_P, _P]),
     ("ptx_read_stats", C.c_int, [_P, C.POINTER(PtxStats)]),
     ("ptx_trace_kernel_name", C.c_char_p, [_P]),

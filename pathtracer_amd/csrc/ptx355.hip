@@ -23,6 +23,7 @@
 #include "post_dev.h"
 #include "bvh_build.h"
 #include "relayout.h"
+#include "collective.h"
 
 #define PTX_BLOCK 256
 #define PT_DEEP_TREE 20u  // stack entries from which a tree counts as deep (millions of primitives): one node visit per WALK step
@@ -294,7 +295,10 @@ PT_DEV void sched_body(const TraceParams& P) {
         }
         if (FRAC) {
             const unsigned long long in_mandel = __ballot(S == LS_MANDEL), in_julia = __ballot(S == LS_JULIA);
-            if (lane == 0u) { est_lanes[0][wave] = in_mandel; est_lanes[1][wave] = in_julia; }
+            if (lane == 0u) {  // read by the other waves' lanes without a barrier: published and read as atomics
+                __hip_atomic_store(&est_lanes[0][wave], in_mandel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&est_lanes[1][wave], in_julia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         if (live == 0u) break;
         const uint32_t single = P.walk_single;  // WALK mode
@@ -316,7 +320,7 @@ PT_DEV void sched_body(const TraceParams& P) {
             if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
         } else {
             const uint32_t n0 = pop[pick];
-            if (FRAC && lane == 0u) est_serving[wave] = pick;
+            if (FRAC && lane == 0u) __hip_atomic_store(&est_serving[wave], pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (;;) {
                 PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(S == pick)));
                 PT_SITE_HIST(60, live);
@@ -336,8 +340,11 @@ PT_DEV void sched_body(const TraceParams& P) {
                         uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                         for (uint32_t k = 1u; k < (uint32_t)PTX_WAVES_PER_BLOCK; k++) {
                             const uint32_t w2 = (wave + k) % (uint32_t)PTX_WAVES_PER_BLOCK;
-                            if (est_serving[w2] == pick) continue;  // that wave's lanes are at their own evaluations now
-                            const unsigned long long m2 = est_lanes[pick - (uint32_t)LS_MANDEL][w2];
+                            // A stale or torn view of either word costs a failed claim, never a wrong result: an evaluation is
+                            // taken by the READY -> BUSY exchange on its own status word, and frac_iterate reads the figure from
+                            // the claimed state, not from the estimator being served here.
+                            if (__hip_atomic_load(&est_serving[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == pick) continue;  // that wave's lanes are at their own evaluations now
+                            const unsigned long long m2 = __hip_atomic_load(&est_lanes[pick - (uint32_t)LS_MANDEL][w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const uint32_t c2 = (uint32_t)__popcll(m2);
                             if (r < c2) {
                                 theirs = fields + (size_t)w2 * kFields * 64u + (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u + nth_set_bit(m2, r);
@@ -355,7 +362,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
                 if (m == 0u || m * 4u < n0 * 3u) break;
             }
-            if (FRAC && lane == 0u) est_serving[wave] = 0u;
+            if (FRAC && lane == 0u) __hip_atomic_store(&est_serving[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     const uint32_t n_bounce = px_u[7 * 64];
@@ -402,8 +409,11 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(cons
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false, PTX_CLAIM_LDS>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true, PTX_CLAIM_LDS>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_sched_kernel(const TraceParams P) { sched_body<false, false>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_sched_kernel_lds(const TraceParams P) { sched_body<true, false>(P); }
+#ifndef PTX_SCHED_WAVES
+#define PTX_SCHED_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel(const TraceParams P) { sched_body<false, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel_lds(const TraceParams P) { sched_body<true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_frac(const TraceParams P) { sched_body<false, true>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_lds_frac(const TraceParams P) { sched_body<true, true>(P); }
 
@@ -621,6 +631,12 @@ struct ptx_ctx {
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
     size_t spill_waves = 0;
     unsigned char* static_scratch = nullptr;  // this device's copy of ptx_static_scratch (its address, not the host-side symbol)
+    // multi-GPU exchange (collective.h)
+    ncclComm_t comm = nullptr;
+    bool comm_owned = false;      // created by ptx_comm_init (destroyed with the context) or handed in by ptx_comm_adopt
+    int comm_rank = 0, comm_world = 1;
+    float* xchg = nullptr;        // slices received from the other ranks
+    size_t xchg_floats = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     std::vector<hipEvent_t> free_events;
@@ -857,6 +873,8 @@ void ptx_destroy(ptx_ctx* c) {
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_scene(c);
     free_frame(c);
+    if (c->comm && c->comm_owned && coll::api()) (void)coll::api()->CommDestroy(c->comm);
+    if (c->xchg) (void)hipFree(c->xchg);
     if (c->stats) (void)hipFree(c->stats);
     if (c->wave_tiles) (void)hipFree(c->wave_tiles);
     if (c->staging) (void)hipFree(c->staging);
@@ -1429,6 +1447,160 @@ int ptx_tonemap(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, const ptx_c
     HIP_TRY(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, c->stream, c->accum, c->out, first_pixel,
                        n_pixels, *cam);
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+
+// ---- multi-GPU exchange over RCCL (collective.h) ---------------------------------------------------------------------
+
+#define NCCL_TRY(ctx, api_, expr)                                                                              \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return fail(ctx, PTX_ERR_HIP, std::string(#expr) + ": " + (api_)->GetErrorString(r_)); \
+    } while (0)
+
+int ptx_comm_unique_id(void* id128) {
+    if (!id128) return PTX_ERR_BAD_ARG;
+    coll::Api* a = coll::api();
+    if (!a) return PTX_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 opaque bytes");
+    ncclUniqueId id;
+    if (a->GetUniqueId(&id) != ncclSuccess) return PTX_ERR_HIP;
+    memcpy(id128, &id, sizeof(id));
+    return PTX_OK;
+}
+
+static int comm_release(ptx_ctx* c) {
+    if (c->comm && c->comm_owned) {
+        coll::Api* a = coll::api();
+        if (a) { (void)hipStreamSynchronize(c->stream); (void)a->CommDestroy(c->comm); }
+    }
+    c->comm = nullptr; c->comm_owned = false; c->comm_rank = 0; c->comm_world = 1;
+    return PTX_OK;
+}
+
+int ptx_comm_init(ptx_ctx* c, const void* id128, uint32_t rank, uint32_t world) {
+    if (!c || !id128) return PTX_ERR_BAD_ARG;
+    if (world == 0 || rank >= world) return fail(c, PTX_ERR_BAD_ARG, "ptx_comm_init: rank outside [0, world)");
+    coll::Api* a = coll::api();
+    if (!a) return fail(c, PTX_ERR_UNSUPPORTED, "ptx_comm_init: " + coll::api_error());
+    HIP_TRY(c, hipSetDevice(c->device));
+    comm_release(c);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCL_TRY(c, a, a->CommInitRank(&c->comm, (int)world, id, (int)rank));
+    c->comm_owned = true; c->comm_rank = (int)rank; c->comm_world = (int)world;
+    return PTX_OK;
+}
+
+int ptx_comm_adopt(ptx_ctx* c, void* nccl_comm) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    comm_release(c);
+    if (!nccl_comm) return PTX_OK;
+    coll::Api* a = coll::api();
+    if (!a) return fail(c, PTX_ERR_UNSUPPORTED, "ptx_comm_adopt: " + coll::api_error());
+    int world = 0, rank = 0;
+    NCCL_TRY(c, a, a->CommCount((ncclComm_t)nccl_comm, &world));
+    NCCL_TRY(c, a, a->CommUserRank((ncclComm_t)nccl_comm, &rank));
+    c->comm = (ncclComm_t)nccl_comm; c->comm_owned = false; c->comm_rank = rank; c->comm_world = world;
+    return PTX_OK;
+}
+
+int ptx_comm_free(ptx_ctx* c) {
+    if (!c) return PTX_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return comm_release(c);
+}
+
+int ptx_merge_sample_split(ptx_ctx* c, const uint32_t* counts, const ptx_camera* cam) {
+    if (!c || !counts || !cam) return PTX_ERR_BAD_ARG;
+    if (!c->comm) return fail(c, PTX_ERR_STATE, "ptx_merge_sample_split before ptx_comm_init / ptx_comm_adopt");
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_merge_sample_split before ptx_resize");
+    coll::Api* a = coll::api();
+    if (!a) return fail(c, PTX_ERR_UNSUPPORTED, "ptx_merge_sample_split: " + coll::api_error());
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t world = (uint32_t)c->comm_world, rank = (uint32_t)c->comm_rank;
+    const uint64_t n = (uint64_t)c->w * c->h;
+    const bool with_m2 = c->moments && c->m2;
+    uint64_t my_first, my_cnt;
+    coll::slice_of(n, world, rank, &my_first, &my_cnt);
+    const size_t need = (size_t)world * my_cnt * (with_m2 ? 7u : 4u);
+    if (need > c->xchg_floats) {
+        if (c->xchg) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->xchg); c->xchg = nullptr; c->xchg_floats = 0; }
+        HIP_TRY(c, hipMalloc((void**)&c->xchg, (need ? need : 4) * sizeof(float)));
+        c->xchg_floats = need;
+    }
+    float* acc = (float*)c->accum;
+    auto recv_a = [&](uint32_t r) { return c->xchg + (size_t)r * my_cnt * 4u; };
+    auto recv_m = [&](uint32_t r) { return c->xchg + (size_t)world * my_cnt * 4u + (size_t)r * my_cnt * 3u; };
+    hipStream_t st = c->stream;
+    // 1. every rank receives its own slice of every rank's partial (its own by a device copy)
+    if (my_cnt) {
+        HIP_TRY(c, hipMemcpyAsync(recv_a(rank), acc + my_first * 4u, my_cnt * 16u, hipMemcpyDeviceToDevice, st));
+        if (with_m2) HIP_TRY(c, hipMemcpyAsync(recv_m(rank), c->m2 + my_first * 3u, my_cnt * 12u, hipMemcpyDeviceToDevice, st));
+    }
+    if (world > 1u) {
+        NCCL_TRY(c, a, a->GroupStart());
+        for (uint32_t j = 0; j < world; j++) {
+            if (j == rank) continue;
+            uint64_t f, k;
+            coll::slice_of(n, world, j, &f, &k);
+            if (k) NCCL_TRY(c, a, a->Send(acc + f * 4u, k * 4u, ncclFloat, (int)j, c->comm, st));
+            if (my_cnt) NCCL_TRY(c, a, a->Recv(recv_a(j), my_cnt * 4u, ncclFloat, (int)j, c->comm, st));
+            if (with_m2) {
+                if (k) NCCL_TRY(c, a, a->Send(c->m2 + f * 3u, k * 3u, ncclFloat, (int)j, c->comm, st));
+                if (my_cnt) NCCL_TRY(c, a, a->Recv(recv_m(j), my_cnt * 3u, ncclFloat, (int)j, c->comm, st));
+            }
+        }
+        NCCL_TRY(c, a, a->GroupEnd());
+    }
+    // 2. Chan's update in fixed rank order: partial 0 is the start, 1, 2, ... are folded in
+    if (my_cnt) {
+        HIP_TRY(c, hipMemcpyAsync(acc + my_first * 4u, recv_a(0), my_cnt * 16u, hipMemcpyDeviceToDevice, st));
+        if (with_m2) HIP_TRY(c, hipMemcpyAsync(c->m2 + my_first * 3u, recv_m(0), my_cnt * 12u, hipMemcpyDeviceToDevice, st));
+        uint64_t n_a = counts[0];
+        for (uint32_t r = 1; r < world; r++) {
+            if (counts[r] == 0u) continue;
+            hipLaunchKernelGGL(ptx_merge_kernel, dim3((uint32_t)((my_cnt + 255u) / 256u)), dim3(256), 0, st, c->accum, with_m2 ? c->m2 : nullptr, c->out,
+                               (uint32_t)my_first, (uint32_t)my_cnt, (float)n_a, (const float4*)recv_a(r), with_m2 ? (const float*)recv_m(r) : nullptr,
+                               (float)counts[r], *cam);
+            HIP_TRY(c, hipGetLastError());
+            n_a += counts[r];
+        }
+    }
+    // 3. the merged slices go to everyone
+    if (world > 1u) {
+        NCCL_TRY(c, a, a->GroupStart());
+        for (uint32_t j = 0; j < world; j++) {
+            if (j == rank) continue;
+            uint64_t f, k;
+            coll::slice_of(n, world, j, &f, &k);
+            if (my_cnt) NCCL_TRY(c, a, a->Send(acc + my_first * 4u, my_cnt * 4u, ncclFloat, (int)j, c->comm, st));
+            if (k) NCCL_TRY(c, a, a->Recv(acc + f * 4u, k * 4u, ncclFloat, (int)j, c->comm, st));
+            if (with_m2) {
+                if (my_cnt) NCCL_TRY(c, a, a->Send(c->m2 + my_first * 3u, my_cnt * 3u, ncclFloat, (int)j, c->comm, st));
+                if (k) NCCL_TRY(c, a, a->Recv(c->m2 + f * 3u, k * 3u, ncclFloat, (int)j, c->comm, st));
+            }
+        }
+        NCCL_TRY(c, a, a->GroupEnd());
+    }
+    // 4. the rgba8 image of the whole frame from the merged means
+    hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, st, c->accum, c->out, 0u, (uint32_t)n, *cam);
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_assemble_tiles(ptx_ctx* c, const ptx_camera* cam) {
+    if (!c || !cam) return PTX_ERR_BAD_ARG;
+    if (!c->comm) return fail(c, PTX_ERR_STATE, "ptx_assemble_tiles before ptx_comm_init / ptx_comm_adopt");
+    if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_assemble_tiles before ptx_resize");
+    coll::Api* a = coll::api();
+    if (!a) return fail(c, PTX_ERR_UNSUPPORTED, "ptx_assemble_tiles: " + coll::api_error());
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t n = (uint64_t)c->w * c->h;
+    // the ranks' buffers are disjoint (untouched pixels are zero), so the sum is exact
+    if (c->comm_world > 1) NCCL_TRY(c, a, a->AllReduce(c->accum, c->accum, n * 4u, ncclFloat, ncclSum, c->comm, c->stream));
+    hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, c->stream, c->accum, c->out, 0u, (uint32_t)n, *cam);
     HIP_TRY(c, hipGetLastError());
     return PTX_OK;
 }

@@ -172,6 +172,32 @@ class PathTracer:
         cam = _arr(cam, CAMERA_DT)
         self._ck(self.lib.ptx_tonemap(self.h, first_pixel, n_pixels, _p(cam)), "ptx_tonemap")
 
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 opaque bytes for ptx_comm_init, made by one rank and carried to the others by the host."""
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().ptx_comm_unique_id(buf)
+        if rc != 0:
+            raise PtxError(f"ptx_comm_unique_id failed ({rc}): RCCL could not be loaded")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._ck(self.lib.ptx_comm_init(self.h, C.c_char_p(unique_id), rank, world), "ptx_comm_init")
+
+    def comm_free(self):
+        self._ck(self.lib.ptx_comm_free(self.h), "ptx_comm_free")
+
+    def merge_sample_split(self, counts, cam):
+        """ptx_merge_sample_split: slice exchange, rank-ordered Chan merge, merged slices to every rank, tonemap."""
+        cam = _arr(cam, CAMERA_DT)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._ck(self.lib.ptx_merge_sample_split(self.h, _p(counts), _p(cam)), "ptx_merge_sample_split")
+
+    def assemble_tiles(self, cam):
+        cam = _arr(cam, CAMERA_DT)
+        self._ck(self.lib.ptx_assemble_tiles(self.h, _p(cam)), "ptx_assemble_tiles")
+
     def post_process(self, params):
         """params: 16 uint32 words (host.build_post_params / ptx_post_params).  Overwrites the rgba8 output."""
         params = np.ascontiguousarray(params, dtype=np.uint32)

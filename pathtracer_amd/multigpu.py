@@ -7,8 +7,12 @@
   Welford moments (n, mean, M2); the partials are exchanged slice-wise (all-to-all), merged with Chan's
   parallel formula in fixed rank order by `ptx_merge_moments`, and the merged slices all-gathered.
 
-`torch.distributed` provides rendezvous and the collectives ("nccl" is RCCL on ROCm; "gloo" on CPU for
-tests); the merge arithmetic for CPU tensors is `chan_merge` below, used by the gloo tests.
+Two implementations of the exchange.  The product's is inside the library (`ptx_merge_sample_split`,
+`ptx_assemble_tiles`: RCCL send/recv groups on the context's stream): `setup_comm` creates its communicator, with
+`torch.distributed` (any backend) only carrying the 128-byte id and serving as the launcher's rendezvous.  The
+second, `merge_sample_split` / `assemble_tiles` below, runs the same steps over `torch.distributed` collectives on
+any "partial" (a GPU context's buffers, or CPU arrays: `HostPartial`), which is how the exchange logic is tested
+on CPU with gloo at world sizes a one-GPU box cannot give RCCL.
 """
 from __future__ import annotations
 
@@ -69,34 +73,97 @@ def device_tensor(ptr: int, shape, dtype, device):
     return torch.as_tensor(raw, device=device)
 
 
+class DevicePartial:
+    """A ptx context's accumulation / M2 buffers as torch tensors on its GPU, merged by `ptx_merge_moments`."""
+
+    def __init__(self, tracer, device):
+        import torch
+        self.tracer, self.device = tracer, device
+        self.n = tracer.width * tracer.height
+        self.acc = device_tensor(tracer.device_accum_ptr(), (self.n, 4), torch.float32, device)
+        m2p = tracer.device_moments_ptr()
+        self.m2 = device_tensor(m2p, (self.n, 3), torch.float32, device) if m2p else None
+
+    def sync(self):
+        import torch
+        self.tracer.sync()
+        torch.cuda.synchronize(self.device)
+
+    def merge(self, first, count, n_a, other_mean4, other_m2, n_b, cam):
+        self.tracer.merge_moments(first, count, n_a, other_mean4.data_ptr(), other_m2.data_ptr() if other_m2 is not None else 0, n_b, cam)
+
+    def tonemap(self, cam):
+        self.tracer.tonemap(0, self.n, cam)
+        self.tracer.sync()
+
+
+class HostPartial:
+    """The same interface over CPU arrays (mean (h, w, 4) and M2 (h, w, 3) float32, e.g. rendered by the CPU oracle):
+    the exchange logic without a GPU.  Merges with `chan_merge`, the device kernel's arithmetic."""
+
+    def __init__(self, accum: np.ndarray, m2: np.ndarray = None):
+        import torch
+        self.device = torch.device("cpu")
+        self.n = accum.shape[0] * accum.shape[1]
+        self.acc = torch.from_numpy(np.ascontiguousarray(accum, dtype=np.float32).reshape(self.n, 4).copy())
+        self.m2 = torch.from_numpy(np.ascontiguousarray(m2, dtype=np.float32).reshape(self.n, 3).copy()) if m2 is not None else None
+
+    def sync(self):
+        pass
+
+    def merge(self, first, count, n_a, other_mean4, other_m2, n_b, cam):
+        if n_b == 0 or count == 0:
+            return
+        a = self.acc[first:first + count].numpy()
+        m = self.m2[first:first + count].numpy() if self.m2 is not None and other_m2 is not None else None
+        _, mean, m2 = chan_merge(n_a, a[:, :3].copy(), m.copy() if m is not None else None, n_b, other_mean4.numpy()[:, :3],
+                                 other_m2.numpy() if m is not None else None)
+        a[:, :3], a[:, 3] = mean, 1.0
+        if m is not None:
+            m[:] = m2
+
+    def tonemap(self, cam):
+        pass
+
+
+def _as_partial(x, device):
+    return x if hasattr(x, "acc") else DevicePartial(x, device)
+
+
+def setup_comm(tracer, dist):
+    """Creates the context's RCCL communicator for the library's own exchange: rank 0 makes the id, the launcher's
+    process group (any backend) carries it."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [tracer.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    tracer.comm_init(box[0], rank, world)
+
+
 def assemble_tiles(tracer, dist, device, cam=None):
-    """Tile partition epilogue: SUM all-reduce of the disjoint accumulation and output buffers."""
+    """Tile partition epilogue over torch.distributed: SUM all-reduce of the disjoint accumulation buffers."""
     import torch
-    tracer.sync()
-    n = tracer.width * tracer.height
-    acc = device_tensor(tracer.device_accum_ptr(), (n * 4,), torch.float32, device)
+    p = _as_partial(tracer, device)
+    p.sync()
+    acc = p.acc.view(-1)
     if _host_staged(dist, device):
         host = acc.cpu()
         dist.all_reduce(host)
         acc.copy_(host)
     else:
         dist.all_reduce(acc)
-    torch.cuda.synchronize(device)
+    p.sync()
     if cam is not None:
-        tracer.tonemap(0, n, cam)
-        tracer.sync()
+        p.tonemap(cam)
 
 
 def merge_sample_split(tracer, dist, device, counts: List[int], cam):
-    """Sample split epilogue.  counts[r] = samples rank r accumulated.  On return every rank holds the
-    merged mean / M2 / output for the whole frame."""
+    """Sample split epilogue over torch.distributed.  counts[r] = samples rank r accumulated.  On return every rank
+    holds the merged mean and M2 of the whole frame (and, for a GPU context, its rgba8 image)."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    tracer.sync()
-    n = tracer.width * tracer.height
-    acc = device_tensor(tracer.device_accum_ptr(), (n, 4), torch.float32, device)
-    m2p = tracer.device_moments_ptr()
-    m2 = device_tensor(m2p, (n, 3), torch.float32, device) if m2p else None
+    p = _as_partial(tracer, device)
+    p.sync()
+    n, acc, m2 = p.n, p.acc, p.m2
     slices = pixel_slices(n, world)
     # slice exchange: rank j receives slice j of every rank's partial
     mine = slices[rank]
@@ -106,31 +173,34 @@ def merge_sample_split(tracer, dist, device, counts: List[int], cam):
     acc[mine[0]:mine[0] + mine[1]].copy_(recv_a[0])
     if m2 is not None:
         m2[mine[0]:mine[0] + mine[1]].copy_(recv_m[0])
-    torch.cuda.synchronize(device)
+    p.sync()
     n_a = counts[0]
     for r in range(1, world):
-        tracer.merge_moments(mine[0], mine[1], n_a, recv_a[r].data_ptr(), recv_m[r].data_ptr() if recv_m else 0, counts[r], cam)
+        p.merge(mine[0], mine[1], n_a, recv_a[r], recv_m[r] if recv_m else None, counts[r], cam)
         n_a += counts[r]
-    tracer.sync()
-    # merged slices back to everyone
-    xdev = torch.device("cpu") if _host_staged(dist, device) else device
-    gathered = [torch.empty((c, 4), dtype=torch.float32, device=xdev) for _, c in slices]
-    merged = acc[mine[0]:mine[0] + mine[1]].contiguous().to(xdev)
-    if len({c for _, c in slices}) == 1:
-        dist.all_gather(gathered, merged)
-    else:
-        _all_gather_uneven(dist, gathered, merged, slices)
-    for (f, c), g in zip(slices, gathered):
-        acc[f:f + c].copy_(g)
-    torch.cuda.synchronize(device)
-    tracer.tonemap(0, n, cam)  # the other ranks' slices arrived as means only
-    tracer.sync()
+    p.sync()
+    # merged slices (means and second moments) back to everyone
+    for buf, width in ((acc, 4), (m2, 3)):
+        if buf is None:
+            continue
+        xdev = torch.device("cpu") if _host_staged(dist, device) else device
+        gathered = [torch.empty((c, width), dtype=torch.float32, device=xdev) for _, c in slices]
+        merged = buf[mine[0]:mine[0] + mine[1]].contiguous().to(xdev)
+        if len({c for _, c in slices}) == 1:
+            dist.all_gather(gathered, merged)
+        else:
+            _all_gather_uneven(dist, gathered, merged, slices)
+        for (f, c), g in zip(slices, gathered):
+            buf[f:f + c].copy_(g)
+    p.sync()
+    p.tonemap(cam)  # the other ranks' slices arrived as means only
     return n_a
 
 
 def _host_staged(dist, device) -> bool:
-    """gloo (the test backend) moves device buffers through host copies made here: its own handling of device
-    tensors stalls now and then when two ranks share one GPU.  RCCL works on the device buffers directly."""
+    """gloo (the test backend) is given host copies of device buffers: it is a CPU backend, and its handling of
+    device tensors stalled now and then with two ranks on one GPU (cause not established; the product's exchange
+    does not go through it)."""
     import torch
     return dist.get_backend() != "nccl" and torch.device(device).type != "cpu"
 
@@ -145,10 +215,11 @@ def _exchange_slices(dist, buf, slices, rank, world, width, device):
         send = [buf[f:f + c].contiguous() for f, c in slices]
         dist.all_to_all(recv, send)
         return recv
-    xdev = torch.device("cpu") if _host_staged(dist, device) else device
+    xdev = torch.device("cpu") if _host_staged(dist, device) else torch.device(device)
     recv = [torch.empty((mine[1], width), dtype=torch.float32, device=xdev) for _ in range(world)]
     send = [buf[f:f + c].contiguous().to(xdev) for f, c in slices]
     for dst in range(world):
+        # gloo's gather wants equally sized tensors: the destination's slice length is what every rank sends
         dist.gather(send[dst], recv if rank == dst else None, dst=dst)
     return [r.to(device) for r in recv]
 

@@ -1,10 +1,12 @@
-"""CPU tier: the N>1 host logic over torch.distributed/gloo with world_size 2 — work split, slice
-exchange and Chan merge — on oracle-rendered partials (no GPU involved)."""
+"""CPU tier: the N>1 host logic over torch.distributed/gloo with world sizes 2 and 3 — work split, uneven slice
+exchange, Chan merge, all-gather of means and second moments, tile assembly — by the functions of
+pathtracer_amd.multigpu themselves on oracle-rendered partials (no GPU involved)."""
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -30,69 +32,74 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, w, h, total):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import host_prep as hp, oracle as orc
+    from pathtracer_amd import multigpu
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sb = hp.prepare_fixture(fixture("cornell_box"))
-    w, h, total = 32, 20, 10
     cam = hp.camera_to_gpu(sb.camera, w, h)
     osc = orc.OracleScene(sb)
-    # --- sample split: this rank renders its frame range, slices are exchanged and merged in rank order
+    # --- sample split: this rank renders its frame range; the exchange is multigpu.merge_sample_split itself
     first, cnt = sample_ranges(total, world)[rank]
     r = orc.render(osc, cam, cnt, first_frame=first, first_sample=1, want_m2=True, threads=1)
-    mean = torch.from_numpy(r["accum"][..., :3].reshape(-1, 3).copy())
-    m2 = torch.from_numpy(r["m2"].reshape(-1, 3).copy())
-    slices = pixel_slices(w * h, world)
-    mine = slices[rank]
-    recv_mean = [torch.empty((mine[1], 3)) for _ in range(world)]
-    recv_m2 = [torch.empty((mine[1], 3)) for _ in range(world)]
-    # gloo has no all_to_all on CPU tensors in every build: use one gather per destination
-    for dst in range(world):
-        f, c = slices[dst]
-        dist.gather(mean[f:f + c].contiguous(), recv_mean if rank == dst else None, dst=dst)
-        dist.gather(m2[f:f + c].contiguous(), recv_m2 if rank == dst else None, dst=dst)
+    part = multigpu.HostPartial(r["accum"], r["m2"])
     counts = [c for _, c in sample_ranges(total, world)]
-    n_acc, a_mean, a_m2 = counts[0], recv_mean[0].numpy(), recv_m2[0].numpy()
-    for rr in range(1, world):
-        n_acc, a_mean, a_m2 = chan_merge(n_acc, a_mean, a_m2, counts[rr], recv_mean[rr].numpy(), recv_m2[rr].numpy())
-    merged = [torch.empty((c, 3)) for _, c in slices]
-    for src in range(world):
-        buf = torch.from_numpy(np.ascontiguousarray(a_mean)) if src == rank else merged[src]
-        dist.broadcast(buf, src=src)
-        merged[src] = buf
-    full_mean = torch.cat(merged).numpy().reshape(h, w, 3)
-    # --- tile partition: disjoint masks, SUM all-reduce assembles the frame
+    n_merged = multigpu.merge_sample_split(part, dist, torch.device("cpu"), counts, cam)
+    full_mean, full_m2 = part.acc.numpy().reshape(h, w, 4).copy(), part.m2.numpy().reshape(h, w, 3).copy()
+    # --- tile partition: disjoint masks, multigpu.assemble_tiles sums them
     mask = owned_blocks(w, h, rank, world)
     one = orc.render(osc, cam, 2, threads=1)["accum"]
-    part = torch.from_numpy(np.where(mask[..., None], one, 0).astype(np.float32))
-    dist.all_reduce(part)
+    tiles = multigpu.HostPartial(np.where(mask[..., None], one, 0).astype(np.float32))
+    multigpu.assemble_tiles(tiles, dist, torch.device("cpu"), cam)
+    # every rank must end with the same frame
+    mine = torch.from_numpy(full_mean.copy())
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    same_everywhere = torch.tensor([1 if torch.equal(mine, ref) else 0])
+    dist.all_reduce(same_everywhere, op=dist.ReduceOp.MIN)
     if rank == 0:
-        q.put((full_mean, part.numpy(), one))
+        q.put((n_merged, full_mean, full_m2, tiles.acc.numpy().reshape(h, w, 4).copy(), one, int(same_everywhere.item())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world_size_2_sample_split_and_tile_partition():
+@pytest.mark.parametrize("world,w,h", [(2, 31, 21), (3, 32, 20)])  # 651 = 2 * 325 + 1 and 640 = 3 * 213 + 1 pixels: uneven slices
+def test_sample_split_and_tile_partition_over_gloo(world, w, h):
     sys.path.insert(0, ROOT)
     from oracle import host_prep as hp, oracle as orc
+    total = 10
+    assert (w * h) % world != 0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, w, h, total)) for r in range(world)]
     for p in procs:
         p.start()
-    full_mean, summed, one = q.get(timeout=120)
+    n_merged, full_mean, full_m2, summed, one, same_everywhere = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert n_merged == total and same_everywhere == 1
     sb = hp.prepare_fixture(fixture("cornell_box"))
-    cam = hp.camera_to_gpu(sb.camera, 32, 20)
-    seq = orc.render(orc.OracleScene(sb), cam, 10, threads=1)["accum"][..., :3]
-    scale = np.maximum(np.abs(seq), 1e-3)
-    assert np.max(np.abs(full_mean - seq) / scale) < 1e-5  # Chan merge vs sequential running mean: rounding only
+    cam = hp.camera_to_gpu(sb.camera, w, h)
+    osc = orc.OracleScene(sb)
+    seq = orc.render(osc, cam, total, threads=1, want_m2=True)
+    scale = np.maximum(np.abs(seq["accum"][..., :3]), 1e-3)
+    assert np.max(np.abs(full_mean[..., :3] - seq["accum"][..., :3]) / scale) < 1e-5  # Chan merge vs sequential running mean: rounding only
+    assert (full_mean[..., 3] == 1).all()
+    # the distributed merge equals the same merge done in one process, bit for bit: means and second moments of the whole frame
+    n_a = mean = m2 = None
+    for first, cnt in sample_ranges(total, world):
+        r = orc.render(osc, cam, cnt, first_frame=first, first_sample=1, want_m2=True, threads=1)
+        if n_a is None:
+            n_a, mean, m2 = cnt, r["accum"][..., :3].copy(), r["m2"].copy()
+        else:
+            n_a, mean, m2 = chan_merge(n_a, mean, m2, cnt, r["accum"][..., :3], r["m2"])
+    assert full_mean[..., :3].tobytes() == mean.tobytes() and full_m2.tobytes() == m2.tobytes()
+    assert np.max(np.abs(full_m2 - seq["m2"]) / np.maximum(np.abs(seq["m2"]), 1e-2)) < 1e-3
     assert summed.tobytes() == one.tobytes()                # disjoint tiles sum to the frame exactly
 
 
