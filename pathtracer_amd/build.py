@@ -50,8 +50,22 @@ def build_host(force: bool = False) -> str:
     return target
 
 
+def build_harness(force: bool = False) -> str:
+    """tools/pt355.cpp: the C++ host over both C ABIs (bin/pt355, finds the libraries next to it through its rpath)."""
+    bindir = os.path.join(HERE, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    target = os.path.join(bindir, "pt355")
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "pt355.cpp")
+    deps = [src, os.path.join(LIB, "libptx355.so"), os.path.join(LIB, "libpthost.so")] + _deps(os.path.join(root, "include"))
+    if force or _stale(target, deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", target, src, "-L" + LIB, "-lptx355", "-lpthost",
+                               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return target
+
+
 def build_all(force: bool = False):
-    return build_device(force), build_host(force)
+    return build_device(force), build_host(force), build_harness(force)
 
 
 if __name__ == "__main__":

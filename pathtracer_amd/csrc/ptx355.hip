@@ -183,7 +183,7 @@ PT_DEV void trace_body(const TraceParams& P) {
                 if (P.m2) { P.m2[J.pix * 3] = px_f[3 * 64]; P.m2[J.pix * 3 + 1] = px_f[4 * 64]; P.m2[J.pix * 3 + 2] = px_f[5 * 64]; }
                 P.out_rgba8[J.pix] = tonemap_rgba8(P.cam, nm);
                 P.primary_ids[J.pix] = px_u[8 * 64];
-                if (P.stats) atomicAdd(&P.stats[0], (unsigned long long)k_next);
+                add_paths(P, k_next);
                 active = CLAIM && claim_pixel(P, job, false, px_f, J);
                 px_u[8 * 64] = 0xFFFFFFFFu;
                 k_next = 0u;

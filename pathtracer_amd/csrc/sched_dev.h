@@ -418,6 +418,13 @@ PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate
     return true;
 }
 
+// Tallies the samples of a finished pixel: one atomic for all the lanes of the wave that finish a pixel together.
+PT_DEV void add_paths(const TraceParams& P, uint32_t samples) {
+    if (!P.stats) return;
+    const unsigned long long m = __ballot(true);
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&P.stats[0], (unsigned long long)samples * (uint32_t)__popcll(m));
+}
+
 // Ends paths and starts new ones: while `ended`, folds the finished sample's radiance into the pixel's running
 // mean (path_trace.wgsl:181, :44-49), writes a finished pixel back and claims the next, and regenerates the
 // camera ray of the next sample (random.wgsl:12-14, camera.wgsl:6-19); then starts the closest-hit traversal of
@@ -466,7 +473,7 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
                 P.accum[J.pix] = make_float4(nm.x, nm.y, nm.z, 1.0f);
                 if (P.m2) { P.m2[J.pix * 3] = px_f[3 * 64]; P.m2[J.pix * 3 + 1] = px_f[4 * 64]; P.m2[J.pix * 3 + 2] = px_f[5 * 64]; }
                 P.out_rgba8[J.pix] = tonemap_rgba8(cam, nm);
-                if (P.stats) atomicAdd(&P.stats[0], (unsigned long long)k_next);
+                add_paths(P, k_next);
                 if (!claim_pixel(P, job, false, px_f, J)) return LS_IDLE;
                 k_next = 0u;
             }

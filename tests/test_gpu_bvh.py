@@ -91,3 +91,24 @@ def test_scene_built_with_the_device_builder_uploads_the_same_buffers(pt, name):
     assert _canon(hb["nodes"]) == _canon(db["nodes"])
     for k in ("figs", "mats", "lights", "infinite", "tex_pixels", "tex_infos"):
         assert hb[k].tobytes() == db[k].tobytes()
+
+
+@pytest.mark.parametrize("n", [40, 9000, 30000])
+def test_zero_bounds_of_either_sign_come_back_as_plus_zero(pt, n):
+    """Boxes that touch the coordinate planes with -0.0 as well as +0.0 bounds, below and above the one-wave range limit:
+    the device builder returns every zero bound as +0.0 (the documented normalisation; min / max of zeros of both signs
+    has no defined sign in the reference's f32::min / f32::max either), all other bits as the host builder's."""
+    a = random_boxes(n, 21, spread=1.0, size=0.05)
+    k = np.arange(n)
+    a[k % 3 == 0, 0] = np.float32(-0.0)    # min x = -0.0
+    a[k % 3 == 1, 0] = np.float32(0.0)     # min x = +0.0
+    a[k % 3 == 0, 3] = np.abs(a[k % 3 == 0, 3]) + np.float32(0.01)
+    a[k % 3 == 1, 3] = np.abs(a[k % 3 == 1, 3]) + np.float32(0.01)
+    a[k % 5 == 0, 4] = np.float32(-0.0)    # max y = -0.0
+    a[k % 5 == 0, 1] = -np.abs(a[k % 5 == 0, 1]) - np.float32(0.01)
+    nodes, prims = pt.bvh_build(a)
+    wn, wp = host.bvh_build(a)
+    assert (prims == wp).all() and _canon(nodes) == _canon(wn)
+    for fld in ("aabb_min", "aabb_max"):
+        v = nodes[fld]
+        assert not (np.signbit(v) & (v == 0)).any()   # no -0.0 leaves the device builder
