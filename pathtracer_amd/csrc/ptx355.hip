@@ -79,7 +79,7 @@ PT_DEV void trace_body(const TraceParams& P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     WalkStack st;
     st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
-    st.glb = P.stack_spill ? P.stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
+    st.glb = walk_stack_glb(P.stack_spill, blockIdx.x * PTX_WAVES_PER_BLOCK + wave, lane);
     st.nl = P.sc.lds_stack_entries;
     DScene sc = P.sc;
     if (LDS_SCENE) {
@@ -219,7 +219,7 @@ PT_DEV void sched_body(const TraceParams& P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     WalkStack st;
     st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
-    st.glb = P.stack_spill ? P.stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
+    st.glb = walk_stack_glb(P.stack_spill, blockIdx.x * PTX_WAVES_PER_BLOCK + wave, lane);
     st.nl = P.sc.lds_stack_entries;
     constexpr uint32_t kFields = SC_PIXEL_FIELDS + SC_PARK_FIELDS + (FRAC ? SC_FRAC_FIELDS : 0u);  // per-lane LDS slots
     float* fields = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u);
@@ -355,7 +355,10 @@ PT_DEV void sched_body(const TraceParams& P) {
                     }
                     float* st = S == pick ? frac : theirs;
                     if (st) (void)frac_iterate(sc, st);  // one pass of the estimator's code for own and adopted evaluations alike
-                    if (S == pick) S = frac_step(sc, tv, pick, P.cam.fractal_march_steps, frac, park, single);
+                    // Lanes of BOTH estimators act on their finished evaluations in every pass, not only those of the estimator
+                    // being served: an evaluation another wave has finished in the meantime is followed by the lane's next one at
+                    // once, which then waits to be taken instead of not existing yet (fractals 1080p, 32 spp: 178 -> 196 Mpaths/s).
+                    if (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA) S = frac_step(sc, tv, S, P.cam.fractal_march_steps, frac, park, single);
                 } else if (S == pick) {
                     S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
                 }
@@ -554,7 +557,7 @@ PT_DEV void kat_trace_body(const DScene& sc, StackEntry* stack_spill, const ptx_
     WalkStack st;
     // the loop variant keeps the whole stack in LDS, the walk variant its first PT_LDS_STACK entries
     st.lds = lds_stack + (size_t)wave * (WALK ? min(sc.stack_entries, PT_LDS_STACK) : sc.stack_entries) * 64u + lane;
-    st.glb = stack_spill ? stack_spill + ((size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + wave) * (31u - PT_LDS_STACK) * 64u + lane : nullptr;
+    st.glb = walk_stack_glb(stack_spill, blockIdx.x * PTX_WAVES_PER_BLOCK + wave, lane);
     st.nl = WALK ? min(sc.stack_entries, PT_LDS_STACK) : sc.stack_entries;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -40,12 +40,20 @@ struct WalkStack {
     StackEntry* glb;  // entry e >= nl at glb[(e - nl) * 64]
     uint32_t nl;      // PT_LDS_STACK, or the whole stack depth for the LDS-staged kernels (no global part)
 };
+// This lane's global-memory stack area inside the launch's spill buffer (one area of (31 - PT_LDS_STACK) x 64 entries per wave).
+PT_DEV StackEntry* walk_stack_glb(StackEntry* spill, uint32_t wave_of_grid, uint32_t lane) {
+    if (!spill) return nullptr;
+    StackEntry* area = spill + (size_t)wave_of_grid * (31u - PT_LDS_STACK) * 64u;
+    return area + lane;  // lane-interleaved like the LDS part (a lane-major layout measured the same on the teapot and the 10 M-triangle scene)
+}
 PT_DEV StackEntry stack_get(const WalkStack& w, int sp) {
-    return (uint32_t)sp < w.nl ? w.lds[sp * 64] : w.glb[(sp - (int)w.nl) * 64];
+    if ((uint32_t)sp < w.nl) return w.lds[sp * 64];
+    PT_SITE(47);
+    return w.glb[(sp - (int)w.nl) * 64];
 }
 PT_DEV void stack_put(const WalkStack& w, int sp, StackEntry e) {
     if ((uint32_t)sp < w.nl) w.lds[sp * 64] = e;
-    else w.glb[(sp - (int)w.nl) * 64] = e;
+    else { PT_SITE(46); w.glb[(sp - (int)w.nl) * 64] = e; }
 }
 
 // Two loop shapes run the same per-lane sequence of box and primitive tests (the reference's):
