@@ -32,6 +32,10 @@
 #ifndef PTX_CLAIM_LDS
 #define PTX_CLAIM_LDS true  // the lockstep LDS kernels claim pixels dynamically
 #endif
+#ifndef FRAC_EXIT_NUM
+#define FRAC_EXIT_NUM 3u  // a marcher is served while at least NUM / DEN of the lanes it started with still march
+#define FRAC_EXIT_DEN 4u
+#endif
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
@@ -302,6 +306,9 @@ PT_DEV void sched_body(const TraceParams& P) {
         }
         if (live == 0u) break;
         const uint32_t single = P.walk_single;  // WALK mode
+#ifdef FRAC_GLUE_TOP
+        if (FRAC && (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA)) S = frac_step(sc, tv, S, P.cam.fractal_march_steps, frac, park, single);
+#endif
         uint32_t pick = fullest;
         if (pop[LS_LEAF] * P.share_leaf >= live) pick = LS_LEAF;
         else if (pop[LS_WALK] * P.share_walk >= live) pick = LS_WALK;
@@ -363,7 +370,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                     S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
                 }
                 const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
-                if (m == 0u || m * 4u < n0 * 3u) break;
+                if (m == 0u || m * FRAC_EXIT_DEN < n0 * FRAC_EXIT_NUM) break;
             }
             if (FRAC && lane == 0u) __hip_atomic_store(&est_serving[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }

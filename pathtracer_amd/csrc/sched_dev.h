@@ -152,6 +152,7 @@ PT_DEV bool frac_iterate(const DScene& sc, float* st) {
     if (!__hip_atomic_compare_exchange_strong(&su[FR_STATUS * 64], &expected, (uint32_t)FS_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_WORKGROUP))
         return false;
+    PT_SITE(48);
     const uint32_t word = su[FR_I * 64];
     const DPrim& g = slot_prim(sc, su[FR_REF * 64]);
     FracIter f;

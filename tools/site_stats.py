@@ -16,7 +16,7 @@ if os.environ.get("PTX355_LIB"):
 from pathtracer_amd.device import PathTracer  # noqa: E402
 
 NAMES = {0: "bounce_step", 1: "walk step", 2: "pair test", 3: "serve round", 30: "plane test", 32: "resolve+shadeA", 33: "NEE setup",
-         34: "NEE eval+shadow", 35: "sample_brdf", 36: "finalize sample", 37: "glass", 43: "POST step", 44: "mandelbulb iteration", 45: "julia iteration", 46: "stack push beyond LDS (8 B)", 47: "stack pop beyond LDS (8 B)", 40: "torus step", 41: "mebius step", 42: "fractal step"}
+         34: "NEE eval+shadow", 35: "sample_brdf", 36: "finalize sample", 37: "glass", 43: "POST step", 44: "mandelbulb iteration", 45: "julia iteration", 48: "evaluation claimed", 46: "stack push beyond LDS (8 B)", 47: "stack pop beyond LDS (8 B)", 40: "torus step", 41: "mebius step", 42: "fractal step"}
 TYPES = ["sphere", "plane", "cube", "cylinder", "cone", "torus", "disc", "triangle", "skybox", "mandelbulb", "julia", "ellipsoid",
          "paraboloid", "hyperboloid", "mebius", "pyramid", "tetrahedron", "nop"]
 for b in range(8):
