@@ -22,12 +22,14 @@
 __device__ unsigned long long pt_sites[PT_NSITES * 2];
 static __device__ __noinline__ void pt_site(int i) {
     unsigned long long m = __ballot(1);
+    if (i < 0 || i >= PT_NSITES) return;
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
         atomicAdd(&pt_sites[2 * i], 1ull);
         atomicAdd(&pt_sites[2 * i + 1], (unsigned long long)__popcll(m));
     }
 }
 static __device__ __noinline__ void pt_site_typed(int base, uint32_t type) {
+    if (base < 0 || base + 18 > PT_NSITES) return;
     for (uint32_t T = 0; T < 18u; T++) {
         unsigned long long m = __ballot((type > 16u ? 17u : type) == T);
         if (m != 0ull && (int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
@@ -36,16 +38,19 @@ static __device__ __noinline__ void pt_site_typed(int base, uint32_t type) {
         }
     }
 }
-static __device__ __noinline__ void pt_site_hist(int base, uint32_t n) {  // histogram of a wave-uniform count 1..64, 8 buckets
+static __device__ __noinline__ void pt_site_hist(int base, uint32_t n) {  // histogram of a wave-uniform count 0..64, 8 buckets (0 counts with 1-8)
     unsigned long long m = __ballot(1);
+    if (base < 0 || base + 8 > PT_NSITES) return;
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
-        int b = base + (int)((n - 1u) >> 3);
+        uint32_t k = n == 0u ? 0u : (n - 1u) >> 3;
+        int b = base + (int)(k > 7u ? 7u : k);
         atomicAdd(&pt_sites[2 * b], 1ull);
         atomicAdd(&pt_sites[2 * b + 1], (unsigned long long)n);
     }
 }
 static __device__ __noinline__ void pt_site_add(int i, uint32_t n) {  // mean of a wave-uniform count
     unsigned long long m = __ballot(1);
+    if (i < 0 || i >= PT_NSITES) return;
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
         atomicAdd(&pt_sites[2 * i], 1ull);
         atomicAdd(&pt_sites[2 * i + 1], (unsigned long long)n);

@@ -32,6 +32,9 @@
 #ifndef PTX_CLAIM_LDS
 #define PTX_CLAIM_LDS true  // the lockstep LDS kernels claim pixels dynamically
 #endif
+#ifndef FRAC_HELD_MIN
+#define FRAC_HELD_MIN 56  // a wave goes on serving an estimator while at least this many of its lanes hold a march (measured: 16 .. 56 rising, flat from 48)
+#endif
 #ifndef FRAC_EXIT_NUM
 #define FRAC_EXIT_NUM 3u  // a marcher is served while at least NUM / DEN of the lanes it started with still march
 #define FRAC_EXIT_DEN 4u
@@ -252,12 +255,12 @@ PT_DEV void sched_body(const TraceParams& P) {
     px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
     px_u[6 * 64] = 0u;  // samples of the current pixel finished
     px_u[7 * 64] = 0u;  // path-bounces, all pixels of this lane
-    // FRAC: which lanes of each wave stand in an estimator (republished every scheduling round), for the other waves'
-    // idle lanes to take evaluations from (sched_dev.h, FS_*); every status word starts idle before any wave looks.
+    // FRAC: which lanes of each wave stand in an estimator, i.e. own a fractal march (republished every scheduling round),
+    // for the other waves' free lanes to take marches from (sched_dev.h, FS_*); every status word starts idle before any wave looks.
     __shared__ unsigned long long est_lanes[2][PTX_WAVES_PER_BLOCK];
     __shared__ uint32_t est_serving[PTX_WAVES_PER_BLOCK];  // the estimator state a wave is serving right now (its own lanes are at their evaluations), or 0
     if (FRAC) {
-        ((uint32_t*)frac)[FR_STATUS * 64] = FS_IDLE;
+        ((uint32_t*)frac)[TK_WORD * 64] = (uint32_t)FS_IDLE << TK_STATUS_SHIFT;
         if (lane == 0u) { est_lanes[0][wave] = 0ull; est_lanes[1][wave] = 0ull; est_serving[wave] = 0u; }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __syncthreads();
@@ -294,6 +297,9 @@ PT_DEV void sched_body(const TraceParams& P) {
         for (uint32_t s = LS_WALK; s < (uint32_t)LS_COUNT; s++) {
             pop[s] = (!FRAC && (s == (uint32_t)LS_MANDEL || s == (uint32_t)LS_JULIA)) ? 0u : (uint32_t)__popcll(__ballot(S == s));
             live += pop[s];
+            // an estimator counts for what can be worked on: owners whose march another wave is running do not call for service
+            if (FRAC && (s == (uint32_t)LS_MANDEL || s == (uint32_t)LS_JULIA))
+                pop[s] = (uint32_t)__popcll(__ballot(S == s && (__hip_atomic_load(&((uint32_t*)frac)[TK_WORD * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> TK_STATUS_SHIFT) != (uint32_t)FS_BUSY));
             if (pop[s] > fullest_n) { fullest_n = pop[s]; fullest = s; }
             if (s >= (uint32_t)LS_TORUS && s <= (uint32_t)LS_JULIA && pop[s] > march_n) { march_n = pop[s]; march = s; }
         }
@@ -306,15 +312,16 @@ PT_DEV void sched_body(const TraceParams& P) {
         }
         if (live == 0u) break;
         const uint32_t single = P.walk_single;  // WALK mode
-#ifdef FRAC_GLUE_TOP
-        if (FRAC && (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA)) S = frac_step(sc, tv, S, P.cam.fractal_march_steps, frac, park, single);
-#endif
+        // FRAC: a march another wave has finished for one of this wave's lanes is acted on whatever state is served next
+        if (FRAC && (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA)) S = task_consume(sc, tv, S, frac, park, single);
         uint32_t pick = fullest;
         if (pop[LS_LEAF] * P.share_leaf >= live) pick = LS_LEAF;
         else if (pop[LS_WALK] * P.share_walk >= live) pick = LS_WALK;
         else if (pop[LS_POST] * P.share_post >= live) pick = LS_POST;
         else if (march_n * P.share_march >= live) pick = march;
-        if (pick == LS_WALK) {
+        if (pick == LS_IDLE) {  // every live lane waits for a march that another wave is running
+            __builtin_amdgcn_s_sleep(8);
+        } else if (pick == LS_WALK) {
             for (;;) {
                 if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, single, frac);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
@@ -327,52 +334,111 @@ PT_DEV void sched_body(const TraceParams& P) {
             if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
         } else {
             const uint32_t n0 = pop[pick];
-            if (FRAC && lane == 0u) __hip_atomic_store(&est_serving[wave], pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (;;) {
-                PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(S == pick)));
-                PT_SITE_HIST(60, live);
-                if (live >= 57u) {  // what a full wave's lanes are doing while a marcher steps
-                    PT_SITE_ADD(70, (uint32_t)__popcll(__ballot(S == LS_WALK)));
-                    PT_SITE_ADD(71, (uint32_t)__popcll(__ballot(S == LS_POST)));
-                    PT_SITE_ADD(72, (uint32_t)__popcll(__ballot(S == LS_MANDEL)));
-                    PT_SITE_ADD(73, (uint32_t)__popcll(__ballot(S == LS_JULIA)));
-                    PT_SITE_ADD(74, (uint32_t)__popcll(__ballot(S == LS_IDLE)));
-                }
-                if (FRAC && pick >= (uint32_t)LS_MANDEL) {
-                    // this wave's lanes outside the estimator run an iteration each for lanes of the workgroup's other waves
-                    // that stand in it: the r-th idle lane takes the r-th such lane, counted from the next wave round
-                    const unsigned long long idle = __ballot(S != pick);
-                    float* theirs = nullptr;
-                    if (S != pick) {
-                        uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (FRAC && pick >= (uint32_t)LS_MANDEL) {
+                // Serving an estimator: every lane of the wave works on a fractal march of that estimator.  A lane that owns one
+                // takes its own; the others (and owners whose march another wave is running) take marches of the workgroup's
+                // other waves.  A march stays in the lane's registers, evaluation after evaluation and marching step after
+                // marching step, until it is finished or the wave turns to other states; a lane whose march finishes takes the next.
+                if (lane == 0u) __hip_atomic_store(&est_serving[wave], pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                float* cur = nullptr;  // the march this lane holds
+                FracTask T;
+                T.ray.o = v3(0.0f, 0.0f, 0.0f); T.ray.d = v3(0.0f, 0.0f, 1.0f);
+                T.m.t = 0.0f; T.m.prev_d = 0.0f; T.m.max_t = 0.0f; T.m.i = 0u;
+                for (int k9 = 0; k9 < 9; k9++) T.f.s[k9] = 0.0f;
+                T.f.i = 0u; T.phase = 0u; T.ref = 0u; T.nacc = v3(0.0f, 0.0f, 0.0f);
+                uint32_t rot = wave * 16u;  // where this wave's free lanes start looking: moves on every pass, differs between waves
+                for (;;) {
+                    PT_SITE_HIST(60, live);
+                    if (live >= 57u) {  // what a full wave's lanes are doing while an estimator is served
+                        PT_SITE_ADD(70, (uint32_t)__popcll(__ballot(S == LS_WALK)));
+                        PT_SITE_ADD(71, (uint32_t)__popcll(__ballot(S == LS_POST)));
+                        PT_SITE_ADD(72, (uint32_t)__popcll(__ballot(S == LS_MANDEL)));
+                        PT_SITE_ADD(73, (uint32_t)__popcll(__ballot(S == LS_JULIA)));
+                        PT_SITE_ADD(74, (uint32_t)__popcll(__ballot(S == LS_IDLE)));
+                    }
+                    // owners of either estimator act on marches that have been finished (by this wave or another)
+                    if (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA) S = task_consume(sc, tv, S, frac, park, single);
+                    // lanes without a march: their own first ...
+                    if (cur == nullptr && S == pick && task_claim(sc, frac, P.cam.fractal_march_steps, T)) cur = frac;
+                    // ... then other waves': the r-th free lane takes the r-th march owner of the waves that are not serving this
+                    // estimator themselves, counted from a moving start.  A stale or torn view of the published words costs a failed
+                    // claim, never a wrong result: a march is taken by the READY -> BUSY exchange on its own status word, and all it
+                    // needs is read from the claimed slot, not from the estimator being served here.
+                    const unsigned long long free_lanes = __ballot(cur == nullptr);
+                    const uint32_t n_free = (uint32_t)__popcll(free_lanes);
+                    if (n_free >= (uint32_t)FRAC_ADOPT_MIN) {
+                        unsigned long long cand[PTX_WAVES_PER_BLOCK - 1];
+                        uint32_t total = 0u;
+#pragma unroll
                         for (uint32_t k = 1u; k < (uint32_t)PTX_WAVES_PER_BLOCK; k++) {
                             const uint32_t w2 = (wave + k) % (uint32_t)PTX_WAVES_PER_BLOCK;
-                            // A stale or torn view of either word costs a failed claim, never a wrong result: an evaluation is
-                            // taken by the READY -> BUSY exchange on its own status word, and frac_iterate reads the figure from
-                            // the claimed state, not from the estimator being served here.
-                            if (__hip_atomic_load(&est_serving[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == pick) continue;  // that wave's lanes are at their own evaluations now
-                            const unsigned long long m2 = __hip_atomic_load(&est_lanes[pick - (uint32_t)LS_MANDEL][w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const uint32_t c2 = (uint32_t)__popcll(m2);
-                            if (r < c2) {
-                                theirs = fields + (size_t)w2 * kFields * 64u + (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u + nth_set_bit(m2, r);
-                                break;
+                            const bool theirs_too = __hip_atomic_load(&est_serving[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == pick;
+                            const unsigned long long seen = theirs_too ? 0ull : __hip_atomic_load(&est_lanes[pick - (uint32_t)LS_MANDEL][w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            // every lane read the same words: as scalars, so that the search below is scalar arithmetic
+                            cand[k - 1u] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seen >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen);
+                            total += (uint32_t)__popcll(cand[k - 1u]);
+                        }
+                        if (cur == nullptr && total > 0u) {
+                            uint32_t r = (uint32_t)__popcll(free_lanes & ((1ull << lane) - 1ull));
+                            if (r < total) {
+                                r += rot;  // rot < total
+                                if (r >= total) r -= total;
+                                float* theirs = nullptr;
+#pragma unroll
+                                for (uint32_t k = 1u; k < (uint32_t)PTX_WAVES_PER_BLOCK; k++) {
+                                    const uint32_t c2 = (uint32_t)__popcll(cand[k - 1u]);
+                                    if (theirs == nullptr) {
+                                        if (r < c2) {
+                                            const uint32_t w2 = (wave + k) % (uint32_t)PTX_WAVES_PER_BLOCK;
+                                            theirs = fields + (size_t)w2 * kFields * 64u + (SC_PIXEL_FIELDS + SC_PARK_FIELDS) * 64u + nth_set_bit(cand[k - 1u], r);
+                                        } else {
+                                            r -= c2;
+                                        }
+                                    }
+                                }
+                                if (theirs && task_claim(sc, theirs, P.cam.fractal_march_steps, T)) cur = theirs;
                             }
-                            r -= c2;
+                        }
+                        rot += n_free;
+                        while (total > 0u && rot >= total) rot -= total;
+                        if (total == 0u) rot = 0u;
+                    }
+                    // a few estimator iterations of every march held; a finished march is published at once
+                    PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(cur != nullptr)));
+                    if (cur != nullptr) {
+                        // the iterations first, for all lanes together; then, once per pass, what the completed evaluations were
+                        // for and the marches' next evaluations (that code runs for the few lanes whose evaluation ended: done after
+                        // every iteration it cost more than the iterations themselves)
+                        const DPrim& g = slot_prim(sc, T.ref);
+                        float value = 0.0f;
+                        bool ended = false;
+                        for (int it = 0; it < FRAC_ITERS_PER_PASS && !ended; it++) ended = frac_eval_iter(g, T.f, value);
+                        if (ended) {
+                            const uint32_t fin = task_advance(sc, T, value, P.cam.fractal_march_steps);
+                            if (fin != 0u) {
+                                task_finish(cur, T, fin);
+                                cur = nullptr;
+                            }
                         }
                     }
-                    float* st = S == pick ? frac : theirs;
-                    if (st) (void)frac_iterate(sc, st);  // one pass of the estimator's code for own and adopted evaluations alike
-                    // Lanes of BOTH estimators act on their finished evaluations in every pass, not only those of the estimator
-                    // being served: an evaluation another wave has finished in the meantime is followed by the lane's next one at
-                    // once, which then waits to be taken instead of not existing yet (fractals 1080p, 32 spp: 178 -> 196 Mpaths/s).
-                    if (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA) S = frac_step(sc, tv, S, P.cam.fractal_march_steps, frac, park, single);
-                } else if (S == pick) {
-                    S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
+                    const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
+                    const uint32_t held = (uint32_t)__popcll(__ballot(cur != nullptr));
+                    if (held < (uint32_t)FRAC_HELD_MIN) break;  // too little held and nothing more to be had: other states, or other waves, have to move first
+                    if (m * FRAC_EXIT_DEN < n0 * FRAC_EXIT_NUM) break;
                 }
-                const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
-                if (m == 0u || m * FRAC_EXIT_DEN < n0 * FRAC_EXIT_NUM) break;
+                if (cur != nullptr) task_store(cur, T, FS_READY);
+                if (S == (uint32_t)LS_MANDEL || S == (uint32_t)LS_JULIA) S = task_consume(sc, tv, S, frac, park, single);
+                if (lane == 0u) __hip_atomic_store(&est_serving[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                for (;;) {
+                    PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(S == pick)));
+                    PT_SITE_HIST(60, live);
+                    if (S == pick) S = march_step<FRAC>(sc, tv, pick, P.cam.fractal_march_steps, single);
+                    const uint32_t m = (uint32_t)__popcll(__ballot(S == pick));
+                    if (m == 0u || m * FRAC_EXIT_DEN < n0 * FRAC_EXIT_NUM) break;
+                }
             }
-            if (FRAC && lane == 0u) __hip_atomic_store(&est_serving[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     const uint32_t n_bounce = px_u[7 * 64];
@@ -1163,7 +1229,8 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     memcpy(sc.root_max, root_max, 12);
     sc.sky_tex = sky_tex;
     memcpy(sc.sky_color, sky_color, 12);
-    uint32_t entries = depth + 1;
+    // a lane's stack holds at most one entry per inner node on the way down; one spare, none for a tree that is a single leaf
+    uint32_t entries = depth == 0u ? 0u : depth + 1;
     sc.stack_entries = entries > 31u ? 31u : entries;
     sc.lds_stack_entries = sc.stack_entries;  // reduced below for the global-memory kernels
     sc.npair = npair;

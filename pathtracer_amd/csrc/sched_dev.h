@@ -59,17 +59,33 @@ enum : uint32_t {
     PK_THR = 13, PK_RAD = 16, PK_RNG = 19, PK_MISC = 20,              // path state; MISC = bounce | csg attempt << 24 | normal ready << 28 | lit << 31
     PK_WO = 21
 };
-// Kernels with the fractal code: the estimator's iteration state (FracIter) follows the parked fields.
-#define SC_FRAC_FIELDS 12u   // FracIter::s[0..8], iterations done | phase << 16, the figure's primitive slot, the evaluation's status
-enum : uint32_t { FR_S = 0, FR_I = 9, FR_REF = 10, FR_STATUS = 11 };
-// An evaluation's status word.  An evaluation is a pure function of its state (FracIter + the figure), and the state
-// lives in LDS, so ANY lane of the workgroup may run its iterations: a wave serving an estimator has most of its lanes
-// idle (they wait in other states), and those lanes take over evaluations of the workgroup's other waves.  Whoever
-// runs an iteration first claims the state (READY -> BUSY) and hands it back (READY, or DONE with the value in
-// FR_S); only the lane that owns the evaluation acts on the result.  The arithmetic does not depend on who ran it.
-enum : uint32_t { FS_IDLE = 0, FS_READY = 1, FS_BUSY = 2, FS_DONE = 3 };
-#ifndef FRAC_ITERS_PER_CLAIM
-#define FRAC_ITERS_PER_CLAIM 6
+// Kernels with the fractal code: a fractal MARCH is a task whose whole state follows the parked fields in LDS: the ray,
+// the marcher's state, the distance estimator's iteration state.  A march is a pure function of that state and the
+// figure, so ANY lane of the workgroup may advance it: evaluation after evaluation, marching step after marching step,
+// until it hits, misses or (for the four evaluations of a normal) is complete.  A wave that serves an estimator has
+// most of its lanes waiting in other states; those lanes take marches of the workgroup's other waves.  Whoever gets to
+// a march first claims it (READY -> BUSY), carries it in registers and hands it back finished (DONE*, result in the
+// slot) or, when its wave turns to other work, unfinished (READY); only the owning lane acts on the result.  The
+// arithmetic, and its order, are those of march_fractal / finish_fractal whoever runs them.
+// The slot holds what cannot be recomputed: 19 words per lane (with 8 pixel and 24 parked words that leaves room for three
+// workgroups per compute unit on a scene whose tree is one leaf; the fourth wave per SIMD the estimators' registers forbid
+// anyway).  Recomputed when a march is claimed, by the very functions that made them: the Julia set's r2 = dot4(z, z)
+// (FracIter::s[8]) and the marcher's max_t (march_begin_fractal).
+#define SC_FRAC_FIELDS 19u
+enum : uint32_t {
+    TK_S = 0,        // FracIter::s[0..7]
+    TK_WORD = 8,     // estimator iterations done | phase << 16 | status << 20: one word, so that a claim is one compare-and-swap
+    TK_REF = 9,      // the figure's primitive slot (slot_prim)
+    TK_O = 10, TK_D = 13,                  // the ray
+    TK_T = 16, TK_PREV = 17, TK_STEP = 18  // MarchState: t (the hit distance when done), prev_d, marching steps done
+};
+#define TK_STATUS_SHIFT 20u
+enum : uint32_t { FS_IDLE = 0, FS_READY = 1, FS_BUSY = 2, FS_DONE_NORMAL = 3, FS_DONE_HIT = 4, FS_DONE_MISS = 5 };
+#ifndef FRAC_ITERS_PER_PASS
+#define FRAC_ITERS_PER_PASS 6   // estimator iterations a serving wave runs between two rounds of claims
+#endif
+#ifndef FRAC_ADOPT_MIN
+#define FRAC_ADOPT_MIN 8        // lanes of a serving wave without a march before they look for other waves' (the search costs all lanes)
 #endif
 // What a fractal evaluation is for: a marching step, the second evaluation of an over-relaxed step, or one of
 // the four evaluations of the winner's normal (torus.wgsl:54-61 pattern in mandelbulb.wgsl:83-93 / julia.wgsl:83-93).
@@ -129,51 +145,13 @@ PT_DEV uint32_t after_prim(const Trav& tv, uint32_t mode) { return mode != 0u &&
 // This wave's LDS operations have completed (the compiler puts no such wait before a workgroup-scope release).
 PT_DEV void lds_drain() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
-// Starts an estimator evaluation at the point of `ray` at distance t (+ `offset`, in the figure's unit space);
-// `ref` is the figure's primitive slot (slot_prim).
-PT_DEV void frac_start(const DPrim& g, uint32_t ref, const Ray& ray, float t, uint32_t phase, V3 offset, float* frac) {
-    const float inv_radius = dm::rcp_(g.p[3]);
-    V3 p = (madd(ray.o, ray.d, t) - v3p(g.p)) * inv_radius;  // march_fractal: p * inv_radius; finish_fractal: local
-    if (phase >= FP_N0) p = p + offset;
-    FracIter f;
-    frac_eval_begin(g, p, f);
-    uint32_t* frac_u = (uint32_t*)frac;
-#pragma unroll
-    for (int k = 0; k < 9; k++) frac[(FR_S + k) * 64] = f.s[k];
-    frac_u[FR_I * 64] = f.i | (phase << 16);
-    frac_u[FR_REF * 64] = ref;
-    lds_drain();
-    __hip_atomic_store(&frac_u[FR_STATUS * 64], (uint32_t)FS_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// One iteration of the evaluation whose state is at `st` (this lane's own or another lane's), if nobody else holds it.
-PT_DEV bool frac_iterate(const DScene& sc, float* st) {
-    uint32_t* su = (uint32_t*)st;
-    uint32_t expected = FS_READY;
-    if (!__hip_atomic_compare_exchange_strong(&su[FR_STATUS * 64], &expected, (uint32_t)FS_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP))
-        return false;
-    PT_SITE(48);
-    const uint32_t word = su[FR_I * 64];
-    const DPrim& g = slot_prim(sc, su[FR_REF * 64]);
-    FracIter f;
-#pragma unroll
-    for (int k = 0; k < 9; k++) f.s[k] = st[(FR_S + k) * 64];
-    f.i = word & 0xFFFFu;
-    float value;
-    uint32_t next = FS_READY;
-    bool done = false;
-    for (int it = 0; it < FRAC_ITERS_PER_CLAIM && !done; it++) done = frac_eval_iter(g, f, value);  // a claim is amortised over a few iterations
-    if (!done) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) st[(FR_S + k) * 64] = f.s[k];
-        su[FR_I * 64] = f.i | (word & 0xFFFF0000u);
-    } else {
-        st[FR_S * 64] = value;
-        next = FS_DONE;
+PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yxy, e.xxx with e = (k, -k)
+    switch (k_index) {
+        case 0: return v3(k, -k, -k);
+        case 1: return v3(-k, -k, k);
+        case 2: return v3(-k, k, -k);
+        default: return v3(k, k, k);
     }
-    lds_drain();
-    __hip_atomic_store(&su[FR_STATUS * 64], next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return true;
 }
 // The r-th set bit of m (r < popcount(m)).
 PT_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
@@ -185,52 +163,124 @@ PT_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
     }
     return pos;
 }
-PT_DEV V3 tet_offset(uint32_t k_index, float k) {  // offsets e.xyy, e.yyx, e.yxy, e.xxx with e = (k, -k)
-    switch (k_index) {
-        case 0: return v3(k, -k, -k);
-        case 1: return v3(-k, -k, k);
-        case 2: return v3(-k, k, -k);
-        default: return v3(k, k, k);
-    }
+
+// A march in registers, while a lane holds it.
+struct FracTask {
+    Ray ray;
+    MarchState m;
+    FracIter f;
+    uint32_t phase, ref;
+    V3 nacc;  // normal tasks: the sum so far (kept in the owner's parked normal while nobody holds the task)
+};
+// Starts the estimator evaluation at distance t along the task's ray (normal phases: offset by their tetrahedron corner,
+// in the figure's unit space): march_fractal's `p * inv_radius`, finish_fractal's `local + o_k`.
+PT_DEV void task_begin_eval(const DPrim& g, FracTask& T, float t, uint32_t phase) {
+    const float inv_radius = dm::rcp_(g.p[3]);
+    V3 p = (madd(T.ray.o, T.ray.d, t) - v3p(g.p)) * inv_radius;
+    if (phase >= FP_N0) p = p + tet_offset(phase - FP_N0, 0.5773f * PT_EPS * 2.0f);
+    frac_eval_begin(g, p, T.f);
+    T.phase = phase;
 }
-// One step of a lane inside a fractal estimator: one iteration and, when the evaluation completes, what the
-// evaluation was for (march_step_fractal's logic around its two sdf calls, or finish_fractal's normal).
-// (The iteration itself is frac_iterate, which the scheduler runs for this lane's evaluation and, in the same
-// instruction stream, for the evaluations its idle lanes have taken over.)
-PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t march_steps, float* frac, float* park, uint32_t mode) {
-    PT_SITE(42);
-    uint32_t* frac_u = (uint32_t*)frac;
-    uint32_t* park_u = (uint32_t*)park;
-    if (__hip_atomic_load(&frac_u[FR_STATUS * 64], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)FS_DONE) return kind;
-    const uint32_t phase = frac_u[FR_I * 64] >> 16, ref = frac_u[FR_REF * 64];
-    const float value = frac[FR_S * 64];
-    frac_u[FR_STATUS * 64] = FS_IDLE;
-    const DPrim& g = slot_prim(sc, ref);
-    if (phase >= FP_N0) {  // finish_fractal / tet_normal: normalize(o0 d0 + o1 d1 + o2 d2 + o3 d3), summed left to right
-        const float k = 0.5773f * PT_EPS * 2.0f;
-        const uint32_t idx = phase - FP_N0;
-        V3 term = tet_offset(idx, k) * value;
-        V3 acc = idx == 0u ? term : v3(park[(PK_N + 0) * 64], park[(PK_N + 1) * 64], park[(PK_N + 2) * 64]) + term;
-        if (idx == 3u) {
-            acc = normalize(acc);
-            park_u[PK_MISC * 64] |= PK_MISC_NORMAL_READY;
-        }
-        park[(PK_N + 0) * 64] = acc.x; park[(PK_N + 1) * 64] = acc.y; park[(PK_N + 2) * 64] = acc.z;
-        if (idx == 3u) return LS_POST;
-        frac_start(g, ref, tv.ray, tv.bound, phase + 1u, tet_offset(idx + 1u, k), frac);
-        return kind;
+// The owning lane's parked fields, seen from a task slot (the fractal fields follow them).
+PT_DEV float* task_park(float* st) { return st - SC_PARK_FIELDS * 64u; }
+PT_DEV void task_store(float* st, const FracTask& T, uint32_t status) {
+    uint32_t* su = (uint32_t*)st;
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[(TK_S + k) * 64] = T.f.s[k];
+    su[TK_REF * 64] = T.ref;
+    st[(TK_O + 0) * 64] = T.ray.o.x; st[(TK_O + 1) * 64] = T.ray.o.y; st[(TK_O + 2) * 64] = T.ray.o.z;
+    st[(TK_D + 0) * 64] = T.ray.d.x; st[(TK_D + 1) * 64] = T.ray.d.y; st[(TK_D + 2) * 64] = T.ray.d.z;
+    st[TK_T * 64] = T.m.t; st[TK_PREV * 64] = T.m.prev_d;
+    su[TK_STEP * 64] = T.m.i;
+    if (T.phase > FP_N0) {  // the normal's partial sum (nothing yet in phase N0)
+        float* pk = task_park(st);
+        pk[(PK_N + 0) * 64] = T.nacc.x; pk[(PK_N + 1) * 64] = T.nacc.y; pk[(PK_N + 2) * 64] = T.nacc.z;
     }
-    // march_step_fractal around the evaluation that just completed
+    lds_drain();
+    __hip_atomic_store(&su[TK_WORD * 64], T.f.i | (T.phase << 16) | (status << TK_STATUS_SHIFT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Takes the march at `st` (this lane's own or another lane's) if it is waiting for someone to run it.
+PT_DEV bool task_claim(const DScene& sc, float* st, uint32_t march_steps, FracTask& T) {
+    uint32_t* su = (uint32_t*)st;
+    uint32_t word = __hip_atomic_load(&su[TK_WORD * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((word >> TK_STATUS_SHIFT) != (uint32_t)FS_READY) return false;
+    const uint32_t busy = (word & ((1u << TK_STATUS_SHIFT) - 1u)) | ((uint32_t)FS_BUSY << TK_STATUS_SHIFT);
+    if (!__hip_atomic_compare_exchange_strong(&su[TK_WORD * 64], &word, busy, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+        return false;
+    PT_SITE(48);
+#pragma unroll
+    for (int k = 0; k < 8; k++) T.f.s[k] = st[(TK_S + k) * 64];
+    T.f.i = word & 0xFFFFu;
+    T.phase = (word >> 16) & 0xFu;
+    T.ref = su[TK_REF * 64];
+    T.ray.o = v3(st[(TK_O + 0) * 64], st[(TK_O + 1) * 64], st[(TK_O + 2) * 64]);
+    T.ray.d = v3(st[(TK_D + 0) * 64], st[(TK_D + 1) * 64], st[(TK_D + 2) * 64]);
+    T.m.t = st[TK_T * 64]; T.m.prev_d = st[TK_PREV * 64];
+    T.m.i = su[TK_STEP * 64];
+    // what the slot leaves out, from the functions that made it
+    const DPrim& g = slot_prim(sc, T.ref);
+    T.f.s[8] = 0.0f;
+    if (g.type == FIG_JULIA) {
+        V4 z; z.x = T.f.s[0]; z.y = T.f.s[1]; z.z = T.f.s[2]; z.w = T.f.s[3];
+        T.f.s[8] = dot4(z, z);
+    }
+    MarchState m0;
+    (void)march_begin_fractal(T.ray, g, march_steps, m0);
+    T.m.max_t = m0.max_t;
+    T.nacc = v3(0.0f, 0.0f, 0.0f);
+    if (T.phase > FP_N0) {
+        const float* pk = task_park(st);
+        T.nacc = v3(pk[(PK_N + 0) * 64], pk[(PK_N + 1) * 64], pk[(PK_N + 2) * 64]);
+    }
+    return true;
+}
+// The owner posts a march of its ray against figure g (primitive slot ref), begun by march_begin_fractal (m), ...
+PT_DEV void task_start_march(const DPrim& g, uint32_t ref, const Ray& ray, const MarchState& m, float* frac) {
+    FracTask T;
+    T.ray = ray;
+    T.m = m;
+    T.ref = ref;
+    T.nacc = v3(0.0f, 0.0f, 0.0f);
+    task_begin_eval(g, T, m.t, FP_D);
+    task_store(frac, T, FS_READY);
+}
+// ... or the four evaluations of the normal at the hit at distance t (finish_fractal / tet_normal).
+PT_DEV void task_start_normal(const DPrim& g, uint32_t ref, const Ray& ray, float t, float* frac) {
+    FracTask T;
+    T.ray = ray;
+    T.m.t = t; T.m.prev_d = 0.0f; T.m.max_t = 0.0f; T.m.i = 0u;
+    T.ref = ref;
+    T.nacc = v3(0.0f, 0.0f, 0.0f);
+    task_begin_eval(g, T, t, FP_N0);
+    task_store(frac, T, FS_READY);
+}
+// An estimator evaluation of a held march has completed with `value`: what the evaluation was for
+// (march_step_fractal's logic around its two sdf calls, or finish_fractal's normal) and the march's next evaluation.
+// Returns 0 while the march goes on, else its final status (FS_DONE_*).
+PT_DEV uint32_t task_advance(const DScene& sc, FracTask& T, float value, uint32_t march_steps) {
+    const DPrim& g = slot_prim(sc, T.ref);
+    PT_SITE(42);
+    if (T.phase >= FP_N0) {  // tet_normal: normalize(o0 d0 + o1 d1 + o2 d2 + o3 d3), summed left to right
+        const uint32_t idx = T.phase - FP_N0;
+        V3 term = tet_offset(idx, 0.5773f * PT_EPS * 2.0f) * value;
+        T.nacc = idx == 0u ? term : T.nacc + term;
+        if (idx == 3u) {
+            T.nacc = normalize(T.nacc);
+            return FS_DONE_NORMAL;
+        }
+        task_begin_eval(g, T, T.m.t, T.phase + 1u);
+        return 0u;
+    }
     const float omega = 1.3f;
     const float radius = g.p[3];
-    MarchState& m = tv.m;
+    MarchState& m = T.m;
     int r = MARCH_GO;
-    if (phase == FP_D) {
+    if (T.phase == FP_D) {
         float d = value * radius;
         if (d < 0.0f && m.prev_d > 0.0f) {
             m.t -= m.prev_d * (omega - 1.0f);
-            frac_start(g, ref, tv.ray, m.t, FP_D2, v3(0.0f, 0.0f, 0.0f), frac);
-            return kind;
+            task_begin_eval(g, T, m.t, FP_D2);
+            return 0u;
         }
         if (dm::abs_(d) < PT_EPS * m.t * 0.5f) r = MARCH_HIT;
         else {
@@ -246,12 +296,36 @@ PT_DEV uint32_t frac_step(const DScene& sc, Trav& tv, uint32_t kind, uint32_t ma
     if (r == MARCH_GO) {
         m.i += 1u;
         if (m.i < march_steps) {
-            frac_start(g, ref, tv.ray, m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
-            return kind;
+            task_begin_eval(g, T, m.t, FP_D);
+            return 0u;
         }
         r = MARCH_MISS;
     }
-    if (trav_apply(sc, tv, r == MARCH_HIT, m.t, 0u)) return LS_POST;
+    return r == MARCH_HIT ? (uint32_t)FS_DONE_HIT : (uint32_t)FS_DONE_MISS;
+}
+// The held march is complete: its result goes where the owning lane looks for it.
+PT_DEV void task_finish(float* st, const FracTask& T, uint32_t status) {
+    if (status == FS_DONE_NORMAL) {
+        float* pk = task_park(st);
+        pk[(PK_N + 0) * 64] = T.nacc.x; pk[(PK_N + 1) * 64] = T.nacc.y; pk[(PK_N + 2) * 64] = T.nacc.z;
+    } else {
+        st[TK_T * 64] = T.m.t;
+    }
+    lds_drain();
+    __hip_atomic_store(&((uint32_t*)st)[TK_WORD * 64], status << TK_STATUS_SHIFT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The owner of a march (a lane in an estimator state) looks at its slot: a finished march is applied to the lane's
+// traversal (or, for a normal, flagged as parked) and the lane moves on.  Returns the lane's next state.
+PT_DEV uint32_t task_consume(const DScene& sc, Trav& tv, uint32_t kind, float* frac, float* park, uint32_t mode) {
+    uint32_t* frac_u = (uint32_t*)frac;
+    const uint32_t status = __hip_atomic_load(&frac_u[TK_WORD * 64], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> TK_STATUS_SHIFT;
+    if (status < (uint32_t)FS_DONE_NORMAL) return kind;
+    frac_u[TK_WORD * 64] = (uint32_t)FS_IDLE << TK_STATUS_SHIFT;
+    if (status == (uint32_t)FS_DONE_NORMAL) {
+        ((uint32_t*)park)[PK_MISC * 64] |= PK_MISC_NORMAL_READY;
+        return LS_POST;
+    }
+    if (trav_apply(sc, tv, status == (uint32_t)FS_DONE_HIT, frac[TK_T * 64], 0u)) return LS_POST;
     tv.pi += 1u;
     return after_prim(tv, mode);
 }
@@ -270,7 +344,7 @@ PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint
         if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
     } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
         if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) {
-            frac_start(g, tv.pi, tv.ray, tv.m.t, FP_D, v3(0.0f, 0.0f, 0.0f), frac);
+            task_start_march(g, tv.pi, tv.ray, tv.m, frac);
             return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
         }
     } else if (type != FIG_SKIP) {
@@ -554,7 +628,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             const DPrim& gw = slot_prim(sc, tv.slot);
             if (gw.type == FIG_MANDELBULB || gw.type == FIG_JULIA) {
                 park_u[PK_MISC * 64] = bounce | (attempt << 24);  // the planes may have moved bound / slot: those live in tv
-                frac_start(gw, tv.slot, tv.ray, tv.bound, FP_N0, tet_offset(0u, 0.5773f * PT_EPS * 2.0f), frac);
+                task_start_normal(gw, tv.slot, tv.ray, tv.bound, frac);
                 return gw.type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
             }
         }
