@@ -407,18 +407,26 @@ PT_DEV void sched_body(const TraceParams& P) {
                     // a few estimator iterations of every march held; a finished march is published at once
                     PT_SITE_HIST(50, (uint32_t)__popcll(__ballot(cur != nullptr)));
                     if (cur != nullptr) {
-                        // the iterations first, for all lanes together; then, once per pass, what the completed evaluations were
-                        // for and the marches' next evaluations (that code runs for the few lanes whose evaluation ended: done after
-                        // every iteration it cost more than the iterations themselves)
+                        // What follows a completed evaluation (what it was for, the march's next evaluation) is code for the few lanes
+                        // whose evaluation has just ended: run after every iteration it cost more than the iterations themselves, run
+                        // once per six iterations it left the finished lanes idle (40 of 55 held marches iterating).
                         const DPrim& g = slot_prim(sc, T.ref);
                         float value = 0.0f;
                         bool ended = false;
-                        for (int it = 0; it < FRAC_ITERS_PER_PASS && !ended; it++) ended = frac_eval_iter(g, T.f, value);
-                        if (ended) {
-                            const uint32_t fin = task_advance(sc, T, value, P.cam.fractal_march_steps);
-                            if (fin != 0u) {
-                                task_finish(cur, T, fin);
-                                cur = nullptr;
+                        // lanes whose evaluation has ended wait for company: the code that follows an evaluation runs when
+                        // FRAC_GLUE_MIN lanes want it (or the pass is over), and those lanes then iterate on with their next evaluation
+                        for (int it = 0; it < FRAC_ITERS_PER_PASS && cur != nullptr; it++) {
+                            if (!ended) ended = frac_eval_iter(g, T.f, value);
+                            const bool last = it + 1 == FRAC_ITERS_PER_PASS;
+                            if ((uint32_t)__popcll(__ballot(ended)) >= (uint32_t)FRAC_GLUE_MIN || last) {
+                                if (ended) {
+                                    const uint32_t fin = task_advance(sc, T, value, P.cam.fractal_march_steps);
+                                    ended = false;
+                                    if (fin != 0u) {
+                                        task_finish(cur, T, fin);
+                                        cur = nullptr;
+                                    }
+                                }
                             }
                         }
                     }

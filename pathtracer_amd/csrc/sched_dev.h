@@ -82,8 +82,11 @@ enum : uint32_t {
 #define TK_STATUS_SHIFT 20u
 enum : uint32_t { FS_IDLE = 0, FS_READY = 1, FS_BUSY = 2, FS_DONE_NORMAL = 3, FS_DONE_HIT = 4, FS_DONE_MISS = 5 };
 #ifndef FRAC_ITERS_PER_PASS
-#define FRAC_ITERS_PER_PASS 6   // estimator iterations a serving wave runs between two rounds of claims
+#define FRAC_ITERS_PER_PASS 24  // estimator iterations a serving wave runs between two rounds of claims
 #endif
+#ifndef FRAC_GLUE_MIN
+#define FRAC_GLUE_MIN 12        // lanes whose evaluation has ended before the code that follows an evaluation is run for them
+#endif                          // (fractals 1080p, 128 spp/launch: 6 iterations + once per pass 262 Mpaths/s; 16/16 277, 12/24 281, 8/24 279, 4/16 264)
 #ifndef FRAC_ADOPT_MIN
 #define FRAC_ADOPT_MIN 8        // lanes of a serving wave without a march before they look for other waves' (the search costs all lanes)
 #endif
