@@ -25,9 +25,7 @@
 #include "relayout.h"
 #include "collective.h"
 
-#define PTX_BLOCK 256
 #define PT_DEEP_TREE 20u  // stack entries from which a tree counts as deep (millions of primitives): one node visit per WALK step
-#define PTX_WAVES_PER_BLOCK 4
 #define PT_PIXEL_FIELDS 9u  // per-lane LDS slots: mean xyz, M2 xyz, sample index, path-bounces, primary id
 #ifndef PTX_CLAIM_LDS
 #define PTX_CLAIM_LDS true  // the lockstep LDS kernels claim pixels dynamically
@@ -44,12 +42,12 @@
 #endif
 
 // Scratch of ptx_trace_n_static, the entry point that allocates nothing: the launch-wide pixel-claim counter, the
-// per-wave claim state and the deep traversal-stack entries of up to PTX_STATIC_MAX_WAVES waves (a 256-CU device
+// per-wave claim records and the deep traversal-stack entries of up to PTX_STATIC_MAX_WAVES waves (a 256-CU device
 // runs at most 4 workgroups of 4 waves per compute unit with these kernels' LDS use).  One copy per device, held
 // from module load to process exit; every call on a device shares it.
 #define PTX_STATIC_MAX_WAVES 4096u
-#define PTX_STATIC_TILES_OFFSET 256u
-#define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_TILES_OFFSET + PTX_STATIC_MAX_WAVES * 8u)
+#define PTX_STATIC_WAVES_OFFSET 256u
+#define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_WAVES_OFFSET + PTX_STATIC_MAX_WAVES * 16u)
 #define PTX_STATIC_BYTES (PTX_STATIC_SPILL_OFFSET + (size_t)PTX_STATIC_MAX_WAVES * (31u - PT_LDS_STACK) * 64u * 8u)
 static __device__ __align__(256) unsigned char ptx_static_scratch[PTX_STATIC_BYTES];
 
@@ -116,6 +114,7 @@ PT_DEV void trace_body(const TraceParams& P) {
                          : (xcd_remap(blockIdx.x, P.n_blocks) << 8) | threadIdx.x;
     PixelJob J;
     bool active = false;
+    wave_claim_init(P);
     px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
     px_u[6 * 64] = 0u;            // k: samples of the current pixel finished
     px_u[7 * 64] = 0u;            // path-bounces
@@ -145,6 +144,7 @@ PT_DEV void trace_body(const TraceParams& P) {
 #ifdef PTX_PHASE_TIMING
     for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
     ps.tick_last = clock64();
+    const unsigned long long wall0 = wall_clock64();
 #endif
     uint32_t local_bounces = 0;
     while (active) {
@@ -206,12 +206,19 @@ PT_DEV void trace_body(const TraceParams& P) {
         PT_TICK(5);
     }
 #ifdef PTX_PHASE_TIMING
-    if (lane == 0u && P.stats)
+    if (lane == 0u && P.stats) {
         for (int i = 0; i < 6; i++) atomicAdd(&P.stats[4 + i], (unsigned long long)ps.tick_acc[i]);
+        const unsigned long long wall1 = wall_clock64();  // 100 MHz
+        atomicMax(&P.stats[10], ~wall0);
+        atomicMax(&P.stats[11], wall1);
+        atomicAdd(&P.stats[12], wall1 - wall0);
+        atomicAdd(&P.stats[13], 1ull);
+    }
 #endif
     const uint32_t n_bounce = px_u[7 * 64];
     uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
-    if (lane == 0u && P.stats) {  // paths were added pixel by pixel
+    flush_paths(P);
+    if (lane == 0u && P.stats) {
         atomicAdd(&P.stats[1], (unsigned long long)sb);
         atomicAdd(&P.stats[2], (unsigned long long)ss);
     }
@@ -274,6 +281,7 @@ PT_DEV void sched_body(const TraceParams& P) {
     tv.have = false; tv.shadow = false;
     tv.m.t = 0.0f; tv.m.prev_d = 0.0f; tv.m.max_t = 0.0f; tv.m.i = 0u;
     uint32_t S = LS_IDLE;
+    wave_claim_init(P);
     uint32_t job = blockIdx.x * PTX_BLOCK + threadIdx.x;  // the first job of every lane; the counter starts behind them
     const bool split = FRAC && P.split_n > 0u;  // jobs are single samples (TraceParams::split_n)
     if (P.n > 0u) {
@@ -452,7 +460,8 @@ PT_DEV void sched_body(const TraceParams& P) {
     const uint32_t n_bounce = px_u[7 * 64];
     uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
     const uint32_t sp = split ? wave_sum(px_u[6 * 64]) : 0u;
-    if (lane == 0u && P.stats) {  // without split jobs the paths were added pixel by pixel
+    if (!split) flush_paths(P);
+    if (lane == 0u && P.stats) {
         if (split) atomicAdd(&P.stats[0], (unsigned long long)sp);
         atomicAdd(&P.stats[1], (unsigned long long)sb);
         atomicAdd(&P.stats[2], (unsigned long long)ss);
@@ -710,10 +719,10 @@ struct ptx_ctx {
     const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
     size_t occ_lds = 0;
     int occ_per_cu = 0;
-    uint2* wave_tiles = nullptr;  // claim state of every wave of the largest grid so far
-    size_t wave_tiles_n = 0;
     StackEntry* spill = nullptr;  // stack entries beyond the LDS part, one area per wave of the largest launch so far
     size_t spill_waves = 0;
+    WaveState* wave_state = nullptr;  // claim record of every wave of the largest grid so far (the kernels initialise their own)
+    size_t wave_state_n = 0;
     unsigned char* static_scratch = nullptr;  // this device's copy of ptx_static_scratch (its address, not the host-side symbol)
     // multi-GPU exchange (collective.h)
     ncclComm_t comm = nullptr;
@@ -960,7 +969,7 @@ void ptx_destroy(ptx_ctx* c) {
     if (c->comm && c->comm_owned && coll::api()) (void)coll::api()->CommDestroy(c->comm);
     if (c->xchg) (void)hipFree(c->xchg);
     if (c->stats) (void)hipFree(c->stats);
-    if (c->wave_tiles) (void)hipFree(c->wave_tiles);
+    if (c->wave_state) (void)hipFree(c->wave_state);
     if (c->staging) (void)hipFree(c->staging);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1362,22 +1371,24 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         int rc = ensure_spill(c, waves, &P.stack_spill);
         if (rc) return rc;
     }
-    if (claim) {
-        if (fixed) {
-            P.wave_tiles = (uint2*)(c->static_scratch + PTX_STATIC_TILES_OFFSET);
-            P.job_counter = (uint32_t*)c->static_scratch;
-        } else {
-            if (waves > c->wave_tiles_n) {
-                if (c->wave_tiles) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->wave_tiles); c->wave_tiles = nullptr; c->wave_tiles_n = 0; }
-                HIP_TRY(c, hipMalloc((void**)&c->wave_tiles, waves * sizeof(uint2)));
-                c->wave_tiles_n = waves;
-            }
-            P.wave_tiles = c->wave_tiles;
-            P.job_counter = (uint32_t*)&c->stats[15];
+    if (fixed) {
+        P.wave_state = (WaveState*)(c->static_scratch + PTX_STATIC_WAVES_OFFSET);
+    } else {
+        if (waves > c->wave_state_n) {
+            if (c->wave_state) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->wave_state); c->wave_state = nullptr; c->wave_state_n = 0; }
+            HIP_TRY(c, hipMalloc((void**)&c->wave_state, waves * sizeof(WaveState)));
+            c->wave_state_n = waves;
         }
-        if (c->claim_tile > 1u) HIP_TRY(c, hipMemsetAsync(P.wave_tiles, 0, waves * sizeof(uint2), c->stream));  // single-pixel claims never touch it
+        P.wave_state = c->wave_state;
+    }
+    if (claim) {
+        P.job_counter = fixed ? (uint32_t*)c->static_scratch : (uint32_t*)&c->stats[15];
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
+        // Lockstep kernels: short launches are bound by the rate of the claims (one device atomic per finished pixel and wave),
+        // long ones lose 4 % when a wave's lanes sit on neighbouring pixels (Cornell box, 1080p: 1.3 ms against 2.0 at one sample
+        // per launch, 15.6 against 17.1 at 16, 30.1 against 29.1 at 32).
+        if (!c->opt.claim_tile && !c->sched && !frac && n <= 16u) P.claim_tile = 64u;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
         if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
@@ -1866,6 +1877,7 @@ int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
     if (rc) return rc;
 #ifdef PTX_PHASE_TIMING
     fprintf(stderr, "phase cycles: closest %llu shadeA %llu shadow %llu shadeB %llu loop-rest %llu finalize %llu\n", v[4], v[5], v[6], v[7], v[8], v[9]);
+    if (v[13]) fprintf(stderr, "waves %llu: first start to last end %.3f ms, mean wave lifetime %.3f ms (lane 0 of each wave)\n", v[13], (double)(v[11] - ~v[10]) * 1e-5, (double)v[12] / (double)v[13] * 1e-5);
 #endif
     out->paths = v[0]; out->bounces = v[1]; out->shadow_rays = v[2];
     return PTX_OK;

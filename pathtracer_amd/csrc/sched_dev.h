@@ -17,6 +17,9 @@
 #pragma once
 #include "trace_dev.h"
 
+#define PTX_BLOCK 256            // lanes per workgroup of the trace kernels
+#define PTX_WAVES_PER_BLOCK 4
+
 // Kernel arguments of the trace kernels (both families).
 struct TraceParams {
     DScene sc;
@@ -30,12 +33,12 @@ struct TraceParams {
     uint32_t* primary_ids;
     float* m2;            // null unless moments are enabled
     StackEntry* stack_spill;  // per-lane stack entries beyond the LDS part (null when none are needed)
+    struct WaveState* wave_state;  // per wave of the grid: its reserved jobs and its path tally (written by the kernel only)
     float* dbg_radiance;  // null unless capture is enabled
     uint32_t dbg_capacity;
     unsigned long long* stats;  // paths, bounces, shadow rays
     uint32_t* job_counter;  // next unclaimed 64-pixel tile of jobs (launch-wide)
-    uint2* wave_tiles;      // per wave of the grid: {next job, end} of the tile it is handing out to its lanes
-    uint32_t claim_tile;    // jobs a wave takes from job_counter at a time: 64, or 1 (lanes claim single pixels directly)
+    uint32_t claim_tile;    // jobs a wave reserves from job_counter at a time: 64, or 1 (just what its lanes need at that moment)
     uint32_t total_jobs;    // n_blocks * 256
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
     uint32_t walk_single;   // scheduled kernels, WALK mode: 0 a step walks to a leaf primitive and tests it; 1 a step is one node visit and
@@ -450,36 +453,64 @@ PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J, bool spli
     J.pix = (size_t)J.py * P.cam.width + J.px;
     return J.tx < P.tile_w && J.ty < P.tile_h;
 }
+// A wave's claim state and path tally: one 16-byte record per wave of the grid in global memory ({next job, end} of the
+// jobs the wave has reserved, paths finished), which only that wave touches -- one lane writes, all its lanes read, in the
+// wave's program order -- through relaxed device-scope atomics, so that neither the compiler nor the per-CU cache keeps an
+// earlier value.  (The trace kernels use every byte of LDS that four workgroups per CU leave: 48 bytes of LDS for this
+// state cost the global-scene kernels a workgroup per CU, 12 % on the 10 M-triangle scene.)
+struct WaveState { uint32_t next, end, paths, pad; };
+PT_DEV WaveState* wave_state(const TraceParams& P) { return P.wave_state + (size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + (threadIdx.x >> 6); }
+PT_DEV void wave_claim_init(const TraceParams& P) {
+    if ((threadIdx.x & 63u) == 0u) {
+        WaveState* ws = wave_state(P);
+        __hip_atomic_store(&ws->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->end, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->paths, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// One job number for every lane that calls (the lanes of a wave whose pixels finished together).  Jobs come from the wave's
+// reserved range; when that runs out the first calling lane takes a new range from the launch-wide counter with ONE device
+// atomic.  Atomics on one address are served one at a time, about 10 ns each on MI355X: with one claim per finished pixel a
+// 1080p frame at one sample per launch spent 2.0 of its 2.2 ms there (and as long again on the path tally, which shared the
+// counter's line).  With claim_tile == 1 a range is exactly what the calling lanes need -- heavy pixels spread over all waves,
+// which serves the fractal scenes (a whole quadrant of silhouette pixels in one wave costs 23 %) and long launches of the
+// Cornell box.  Otherwise a range is claim_tile jobs (64: one 8x8 quadrant, so the lanes of a wave stay on neighbouring
+// pixels, which serves meshes and the Moebius marcher: +4 % / +18 %).  Ranges that shrink with the work left, to even out the
+// end of the launch, measured slower (Cornell box, one sample per launch: 1.5 ms against 1.3).
+PT_DEV uint32_t claim_jobs(const TraceParams& P) {
+    const unsigned long long need = __ballot(true);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = (uint32_t)__popcll(need), rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+    const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
+    if (P.claim_tile <= 1u) {  // no reserve to keep: the wave's state is not touched
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(P.job_counter, cnt);
+        return (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) + rank;
+    }
+    WaveState* ws = wave_state(P);
+    const uint32_t next = __hip_atomic_load(&ws->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t end = __hip_atomic_load(&ws->end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t avail = end - next;
+    if (cnt <= avail) {
+        if (lane == leader) __hip_atomic_store(&ws->next, next + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return next + rank;
+    }
+    const uint32_t want = cnt - avail;
+    const uint32_t chunk = want > P.claim_tile ? want : P.claim_tile;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(P.job_counter, chunk);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    if (lane == leader) {
+        __hip_atomic_store(&ws->next, base + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->end, base + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return rank < avail ? next + rank : base + (rank - avail);
+}
 // Claims jobs until one lies inside the tile; loads that pixel's accumulator into the lane's LDS slots.
-// With claim_tile == 64 a wave takes jobs from the launch-wide counter 64 at a time (one 8x8 quadrant: one
-// device-scope atomic per 64 pixels) and hands them to its lanes from its own {next, end} pair, which only this
-// wave touches (lanes of a wave never run concurrently with each other, so the pair needs no stronger than
-// workgroup-scope atomics): the lanes of a wave stay on neighbouring pixels, which serves meshes and the Moebius
-// marcher (+4 % / +18 %).  With claim_tile == 1 every lane claims single pixels from the counter: heavy pixels
-// spread over all waves, which serves the fractal scenes (a whole quadrant of silhouette pixels in one wave
-// costs 23 %) and, slightly, the Cornell box.
 PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate, float* px_f, PixelJob& J, bool split = false) {
     uint32_t* px_u = (uint32_t*)px_f;
-    uint2* wt = P.wave_tiles + (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     for (;;) {
-        if (!have_candidate && P.claim_tile <= 1u) {
-            job = atomicAdd(P.job_counter, 1u);
-        } else if (!have_candidate) {
-            job = __hip_atomic_fetch_add(&wt->x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t end = __hip_atomic_load(&wt->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (job >= end) {  // the wave's tile is used up: the first of the lanes standing here fetches the next
-                const unsigned long long need = __ballot(true);
-                const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)need) - 1u;
-                uint32_t base = 0u;
-                if (lane == leader) {
-                    base = atomicAdd(P.job_counter, P.claim_tile);
-                    __hip_atomic_store(&wt->y, base + P.claim_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&wt->x, base + (uint32_t)__popcll(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                base = (uint32_t)__shfl((int)base, (int)leader, 64);
-                job = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            }
-        }
+        if (!have_candidate) job = claim_jobs(P);
         have_candidate = false;
         if (job >= P.total_jobs) return false;
         if (job_pixel(P, job, J, split)) break;
@@ -496,11 +527,16 @@ PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate
     return true;
 }
 
-// Tallies the samples of a finished pixel: one atomic for all the lanes of the wave that finish a pixel together.
+// Tallies the samples of a finished pixel for all the lanes of the wave that finish a pixel together (in the wave's own
+// record: the launch-wide tally takes one atomic per wave, at its end).
 PT_DEV void add_paths(const TraceParams& P, uint32_t samples) {
-    if (!P.stats) return;
     const unsigned long long m = __ballot(true);
-    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&P.stats[0], (unsigned long long)samples * (uint32_t)__popcll(m));
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u)
+        __hip_atomic_fetch_add(&wave_state(P)->paths, samples * (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PT_DEV void flush_paths(const TraceParams& P) {
+    if ((threadIdx.x & 63u) == 0u && P.stats)
+        atomicAdd(&P.stats[0], (unsigned long long)__hip_atomic_load(&wave_state(P)->paths, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // Ends paths and starts new ones: while `ended`, folds the finished sample's radiance into the pixel's running

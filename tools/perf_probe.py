@@ -10,7 +10,8 @@ if os.environ.get("PTX355_LIB"):  # A/B of differently built libraries
     _lib.LIB_PATH = os.path.abspath(os.environ["PTX355_LIB"])
 from pathtracer_amd.device import PathTracer  # noqa: E402
 
-CASES = [("cornell_box", 1920, 1080, (32, 128)), ("teapot", 3840, 2160, (8,)), ("fractals", 1920, 1080, (2,)), ("all", 1920, 1080, (16,))]
+CASES = [("cornell_box", 1920, 1080, (32, 128)), ("teapot", 3840, 2160, (8,)), ("fractals", 1920, 1080, (2,)), ("all", 1920, 1080, (16,)),
+         ("all_mesh", 1920, 1080, (8,))]  # all_mesh: all.yaml + the 10 M-triangle height field of bench.py --workload all_mesh
 print("library:", _lib.LIB_PATH)
 if len(sys.argv) > 1:
     CASES = [c for c in CASES if c[0] in sys.argv[1:]]
@@ -22,7 +23,12 @@ for kv in filter(None, os.environ.get("PROBE_OPTS", "").split(",")):
     k, v = kv.split("=")
     pt.set_option(k, int(v))
 for name, w, h, ns in CASES:
-    sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
+    if name == "all_mesh":
+        sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", "all.npz"))
+        sc.append_heightfield(2236)
+        sc.build(decode_textures=False, tracer=pt)
+    else:
+        sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
     cam = sc.camera(w, h)
     sc.upload_to(pt)
     pt.resize(w, h)
