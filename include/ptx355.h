@@ -95,7 +95,7 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  * upload_path, which the next ptx_upload_scene reads.  Keys and values:
  *   kernel_family  -1 per scene (default), 0 lockstep kernels, 1 wave-scheduled kernels
  *   upload_path    -1 by scene size, 0 record re-layout on the host, 1 on the device
- *   claim_tile      0 per scene, 1 or 64 pixel jobs per claim
+ *   claim_tile      0 per scene and launch; pixel jobs a wave reserves per claim: 1, or a power of two from 16 to 1024
  *   split_samples   1 (default) / 0: sample-granular jobs + fold for fractal scenes
  *   split_chunk     0 = bounded by the staging buffer, else samples per chunk
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes

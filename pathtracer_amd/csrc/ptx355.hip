@@ -987,7 +987,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     bool ok = true;
     if (k == "kernel_family") { if ((ok = in(-1, 1))) o.family = (int)value; }
     else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
-    else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || value == 64)) o.claim_tile = (uint32_t)value; }
+    else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || (value >= 16 && value <= 1024 && (value & (value - 1)) == 0))) o.claim_tile = (uint32_t)value; }
     else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
     else if (k == "split_chunk") { if ((ok = in(0, 0x7FFFFFFF))) o.split_chunk = (uint32_t)value; }
     else if (k == "share_walk") { if ((ok = in(0, 64))) o.shares[0] = (uint32_t)value; }
@@ -1054,7 +1054,7 @@ static int configure(ptx_ctx* c) {
         if (c->opt.shares[i]) c->shares[i] = c->opt.shares[i];
     if (c->opt.shares[3]) c->share_leaf = c->opt.shares[3];
     c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
-    if (c->opt.claim_tile) c->claim_tile = c->opt.claim_tile > 1u ? 64u : 1u;
+    if (c->opt.claim_tile) c->claim_tile = c->opt.claim_tile;
     // Resident workgroups per compute unit of the kernel this scene runs: the claiming kernels' grid.
     const TraceKernel kernel = trace_kernel_of(c);
     const size_t lds_all = trace_lds_bytes(c);
@@ -1389,6 +1389,10 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         // long ones lose 4 % when a wave's lanes sit on neighbouring pixels (Cornell box, 1080p: 1.3 ms against 2.0 at one sample
         // per launch, 15.6 against 17.1 at 16, 30.1 against 29.1 at 32).
         if (!c->opt.claim_tile && !c->sched && !frac && n <= 16u) P.claim_tile = 64u;
+        // Scheduled kernels on frames of 4 M pixels and more, one or two samples per launch: even one claim per 64 pixels is
+        // 130 k atomics on one address (teapot 4K, one sample per launch: 2.1 ms, 1.7 ms with 128 pixels per claim; longer
+        // launches and smaller frames are 3-6 % faster with 64).
+        if (!c->opt.claim_tile && c->sched && !frac && n <= 2u && P.n_blocks >= 16384u) P.claim_tile = 128u;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
         if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
@@ -1425,7 +1429,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     for (uint32_t done = 0; done < n; done += chunk) {
         const uint32_t m = n - done < chunk ? n - done : chunk;
         P.first_frame = first_frame + done; P.first_sample = first_sample + done; P.n = m;
-        if (split && m > 1u) { P.split_n = m; P.total_jobs = P.n_blocks * 256u * m; }
+        if (split && m > 1u) { P.split_n = m; P.total_jobs = P.n_blocks * 256u * m; if (!c->opt.claim_tile) P.claim_tile = m >= 64u ? 256u : 128u; }
         else { P.split_n = 0u; P.total_jobs = P.n_blocks * 256u; }
         if (claim) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
