@@ -14,3 +14,8 @@ PTX355_LIB=pathtracer_amd/lib/diag/libptx355_sites.so timeout -k 10 120 python3 
 PTX355_LIB=pathtracer_amd/lib/diag/libptx355_sites.so timeout -k 10 300 python3 tools/site_stats.py fractals 1920 1080 8 > $O/sites_fractals.txt 2>&1 || { echo "site stats failed"; tail -5 $O/sites_fractals.txt; exit 1; }
 bash tools/profile_r02.sh fractals > $O/prof_fractals.txt 2>&1 || { echo "fractal profile failed"; tail -5 $O/prof_fractals.txt; exit 1; }
 tail -3 $O/prof_fractals.txt
+for W in cornell teapot all_mesh; do
+  bash tools/profile_r02.sh $W > $O/prof_$W.txt 2>&1 || { echo "$W profile failed"; tail -5 $O/prof_$W.txt; exit 1; }
+  tail -1 $O/prof_$W.txt
+done
+PTX355_LIB=pathtracer_amd/lib/diag/libptx355_phase.so PROBE_N=1,128 timeout -k 10 120 python3 tools/perf_probe.py cornell_box > $O/phase_cornell.txt 2>&1 || { echo "phase probe failed"; exit 1; }
