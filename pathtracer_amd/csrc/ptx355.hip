@@ -45,6 +45,8 @@
 // per-wave claim records and the deep traversal-stack entries of up to PTX_STATIC_MAX_WAVES waves (a 256-CU device
 // runs at most 4 workgroups of 4 waves per compute unit with these kernels' LDS use).  One copy per device, held
 // from module load to process exit; every call on a device shares it.
+#define PTX_FLIGHTS 8  // launches of sample-granular jobs that may be in flight at once (their staging buffers: 8 GiB together at most)
+#define PTX_FLIGHTS_DEFAULT 6u
 #define PTX_STATIC_MAX_WAVES 4096u
 #define PTX_STATIC_WAVES_OFFSET 256u
 #define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_WAVES_OFFSET + PTX_STATIC_MAX_WAVES * 16u)
@@ -494,6 +496,7 @@ extern "C" __global__ void __launch_bounds__(256) ptx_fold_kernel(const TracePar
     P.accum[J.pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
     if (P.m2) { P.m2[J.pix * 3] = m2.x; P.m2[J.pix * 3 + 1] = m2.y; P.m2[J.pix * 3 + 2] = m2.z; }
     P.out_rgba8[J.pix] = tonemap_rgba8(P.cam, mean);
+    P.primary_ids[J.pix] = __float_as_uint(P.staging[(size_t)(P.n - 1u) * P.frame_pixels + J.pix].w);
 }
 
 // Four variants: scene records in global memory or staged in LDS; with or without the fractal marchers.
@@ -712,10 +715,26 @@ struct ptx_ctx {
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
+        uint32_t flights = 0;     // launches of sample-granular jobs in flight at once; 0 = as many as the staging bound allows (at most PTX_FLIGHTS)
         bool verbose = false, bvh_timing = false;
     } opt;
-    float4* staging = nullptr;    // their staged samples, [sample][frame pixel]
-    size_t staging_n = 0;
+    // Launches of sample-granular jobs in flight (launch_trace): each traces on a stream of its own into a staging buffer of
+    // its own; the folds follow one another on `stream`.
+    struct Flight {
+        hipStream_t stream = nullptr;
+        hipEvent_t traced = nullptr, folded = nullptr;  // its trace kernel / the fold of its staging buffer has finished
+        bool used = false;
+        float4* staging = nullptr;  // staged samples, [sample][frame pixel]: radiance in xyz, the primary hit's figure in w
+        size_t staging_n = 0;
+        WaveState* wave_state = nullptr;
+        size_t wave_state_n = 0;
+    };
+    Flight flights[PTX_FLIGHTS];
+    uint32_t flight_seq = 0;
+    uint32_t* flight_counters = nullptr;  // one job counter per flight, 256 bytes apart
+    hipEvent_t barrier = nullptr;         // everything enqueued on `stream` by calls other than those launches, up to the last of them
+    hipEvent_t last_traced = nullptr;     // the latest flight's trace (flights that share the deep-stack area run one after the other)
+    bool order_dirty = true;              // such a call has been made since `barrier` was recorded
     const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
     size_t occ_lds = 0;
     int occ_per_cu = 0;
@@ -769,6 +788,11 @@ void free_frame(ptx_ctx* c) {
     if (c->dbg) (void)hipFree(c->dbg);
     c->accum = nullptr; c->out = nullptr; c->ids = nullptr; c->m2 = nullptr; c->dbg = nullptr;
     c->dbg_cap = 0;
+    for (auto& f : c->flights) {  // callers have drained `stream`, whose folds wait for every trace
+        if (f.staging) (void)hipFree(f.staging);
+        f.staging = nullptr; f.staging_n = 0;
+    }
+    c->order_dirty = true;
 }
 
 // Makes room for the deep stack entries of `waves` waves (only scenes whose tree is deeper than PT_LDS_STACK
@@ -970,7 +994,14 @@ void ptx_destroy(ptx_ctx* c) {
     if (c->xchg) (void)hipFree(c->xchg);
     if (c->stats) (void)hipFree(c->stats);
     if (c->wave_state) (void)hipFree(c->wave_state);
-    if (c->staging) (void)hipFree(c->staging);
+    for (auto& f : c->flights) {
+        if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
+        if (f.traced) (void)hipEventDestroy(f.traced);
+        if (f.folded) (void)hipEventDestroy(f.folded);
+        if (f.wave_state) (void)hipFree(f.wave_state);
+    }
+    if (c->flight_counters) (void)hipFree(c->flight_counters);
+    if (c->barrier) (void)hipEventDestroy(c->barrier);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -996,6 +1027,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
     else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
     else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
+    else if (k == "flights") { if ((ok = in(0, PTX_FLIGHTS))) o.flights = (uint32_t)value; }
     else if (k == "verbose") { o.verbose = value != 0; }
     else if (k == "bvh_timing") { o.bvh_timing = value != 0; }
     else return fail(c, PTX_ERR_BAD_ARG, "ptx_set_option: unknown key '" + k + "'");
@@ -1072,6 +1104,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
                      const ptx_bvh_node* nodes, uint32_t nnode, const uint32_t* prims, uint32_t nprim,
                      const uint32_t* lights, uint32_t nlight, const uint32_t* infinite, uint32_t ninf,
                      const uint32_t* tex_pixels, uint32_t npix, const ptx_texture_info* tex_infos, uint32_t ntex) {
+    if (c) c->order_dirty = true;
     if (!c) return PTX_ERR_BAD_ARG;
     if ((nfig && !figs) || (nmat && !mats) || (nnode && !nodes) || (nprim && !prims) || (nlight && !lights) ||
         (ninf && !infinite) || (npix && !tex_pixels) || (ntex && !tex_infos))
@@ -1306,6 +1339,7 @@ int ptx_set_partition(ptx_ctx* c, uint32_t rank, uint32_t world) {
 }
 
 int ptx_clear(ptx_ctx* c) {
+    if (c) c->order_dirty = true;
     if (!c) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_clear before ptx_resize");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1401,23 +1435,32 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Fractal scenes: a pixel on a fractal's silhouette costs hundreds of times a background pixel, and with one
     // lane folding all n samples of its pixel the launch ends on a few lanes finishing theirs.  There the jobs
     // are single samples, staged and folded in order by ptx_fold_kernel, in chunks that bound the staging buffer
-    // (4 GiB of the 288: 128 samples of a 1080p frame; the launch's fixed cost, its last waves draining, is paid per chunk) and the job count.  Radiance capture keeps whole-pixel jobs (its sample index is launch-relative).
-    const bool split = !fixed && c->sched && frac && c->split && n > 1u && !c->dbg;
+    // (4 GiB of the 288: 128 samples of a 1080p frame) and the job count.  Radiance capture keeps whole-pixel jobs
+    // (its sample index is launch-relative).
+    // Such a launch still ends on its longest paths (tens of milliseconds of a few lanes marching), and it reads nothing
+    // an earlier launch writes: so every chunk traces on a stream of its own (a "flight") into a staging buffer of its own,
+    // beside the tails of the chunks and calls before it, and only the folds follow one another, on the context's stream.
+    const bool split = !fixed && c->sched && frac && c->split && !c->dbg;
     uint32_t chunk = n;
+    size_t frame_pixels = 0;
+    uint32_t depth = 1;
     if (split) {
-        const size_t frame_pixels = (size_t)c->w * c->h;
+        frame_pixels = (size_t)c->w * c->h;
         size_t by_mem = ((size_t)4 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)P.n_blocks * 256u);
         size_t m = by_mem < by_jobs ? by_mem : by_jobs;
         if (c->opt.split_chunk >= 1u && c->opt.split_chunk < m) m = c->opt.split_chunk;
         if (m < 1) m = 1;
         if (m < chunk) chunk = (uint32_t)m;
-        if (chunk * frame_pixels > c->staging_n) {
-            if (c->staging) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->staging); c->staging = nullptr; c->staging_n = 0; }
-            HIP_TRY(c, hipMalloc((void**)&c->staging, chunk * frame_pixels * sizeof(float4)));
-            c->staging_n = chunk * frame_pixels;
-        }
-        P.staging = c->staging;
         P.frame_pixels = (uint32_t)frame_pixels;
+        const size_t in_flight = ((size_t)8 << 30) / (chunk * frame_pixels * sizeof(float4));
+        // measured, fractals 1080p, one sample per launch, ms per frame with 1 / 2 / 4 / 6 / 8 in flight: 58 / 28.5 / 29 / 20.6 / 21.9
+        // (HIP's default of four hardware queues per process; with GPU_MAX_HW_QUEUES=8 in the host's environment: 58 / 27.5 / 17.4 / 14.1 / 16.8)
+        depth = in_flight >= PTX_FLIGHTS_DEFAULT ? PTX_FLIGHTS_DEFAULT : (in_flight < 2 ? 2u : (uint32_t)in_flight);
+        if (c->opt.flights >= 1u) depth = c->opt.flights < in_flight || c->opt.flights <= 2u ? c->opt.flights : (in_flight < 2 ? 2u : (uint32_t)in_flight);
+        if (!c->flight_counters) HIP_TRY(c, hipMalloc((void**)&c->flight_counters, PTX_FLIGHTS * 256));
+        if (!c->barrier) HIP_TRY(c, hipEventCreateWithFlags(&c->barrier, hipEventDisableTiming));
+    } else {
+        c->order_dirty = true;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!fixed) {
@@ -1429,17 +1472,57 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     for (uint32_t done = 0; done < n; done += chunk) {
         const uint32_t m = n - done < chunk ? n - done : chunk;
         P.first_frame = first_frame + done; P.first_sample = first_sample + done; P.n = m;
-        if (split && m > 1u) { P.split_n = m; P.total_jobs = P.n_blocks * 256u * m; if (!c->opt.claim_tile) P.claim_tile = m >= 64u ? 256u : 128u; }
-        else { P.split_n = 0u; P.total_jobs = P.n_blocks * 256u; }
-        if (claim) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
-        HIP_TRY(c, hipGetLastError());
-        if (P.split_n > 0u) {
-            TraceParams F = P;
-            F.split_n = 0u;
-            hipLaunchKernelGGL(ptx_fold_kernel, dim3(P.n_blocks), dim3(256), 0, c->stream, F);
+        if (!split) {
+            P.split_n = 0u; P.total_jobs = P.n_blocks * 256u;
+            if (claim) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
             HIP_TRY(c, hipGetLastError());
+            continue;
         }
+        P.split_n = m; P.total_jobs = P.n_blocks * 256u * m;
+        if (!c->opt.claim_tile) P.claim_tile = m >= 64u ? 256u : 128u;
+        ptx_ctx::Flight& f = c->flights[c->flight_seq % depth];
+        const uint32_t slot = (uint32_t)(&f - c->flights);
+        if (!f.stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&f.traced, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&f.folded, hipEventDisableTiming));
+        }
+        if ((size_t)m * frame_pixels > f.staging_n || waves > f.wave_state_n) {  // grow: not while the flight's last launch uses them
+            if (f.used) HIP_TRY(c, hipEventSynchronize(f.folded));
+            if ((size_t)m * frame_pixels > f.staging_n) {
+                if (f.staging) { (void)hipFree(f.staging); f.staging = nullptr; f.staging_n = 0; }
+                HIP_TRY(c, hipMalloc((void**)&f.staging, (size_t)m * frame_pixels * sizeof(float4)));
+                f.staging_n = (size_t)m * frame_pixels;
+            }
+            if (waves > f.wave_state_n) {
+                if (f.wave_state) { (void)hipFree(f.wave_state); f.wave_state = nullptr; f.wave_state_n = 0; }
+                HIP_TRY(c, hipMalloc((void**)&f.wave_state, waves * sizeof(WaveState)));
+                f.wave_state_n = waves;
+            }
+        }
+        // order: after whatever other calls have enqueued on the context's stream (a clear, an upload, other kernels); after the
+        // fold that read this flight's staging buffer last; after the previous flight's trace if they share the deep-stack area
+        if (c->order_dirty) { HIP_TRY(c, hipEventRecord(c->barrier, c->stream)); c->order_dirty = false; }
+        HIP_TRY(c, hipStreamWaitEvent(f.stream, c->barrier, 0));
+        if (f.used) HIP_TRY(c, hipStreamWaitEvent(f.stream, f.folded, 0));
+        if (P.stack_spill && c->last_traced) HIP_TRY(c, hipStreamWaitEvent(f.stream, c->last_traced, 0));
+        P.staging = f.staging;
+        P.wave_state = f.wave_state;
+        P.job_counter = c->flight_counters + slot * 64u;
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, f.stream));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, f.stream, P);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(f.traced, f.stream));
+        c->last_traced = f.traced;
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, f.traced, 0));
+        TraceParams F = P;
+        F.split_n = 0u;
+        hipLaunchKernelGGL(ptx_fold_kernel, dim3(P.n_blocks), dim3(256), 0, c->stream, F);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(f.folded, c->stream));
+        f.used = true;
+        c->flight_seq += 1u;
     }
     if (!fixed) {
         HIP_TRY(c, hipEventRecord(e1, c->stream));
@@ -1478,6 +1561,7 @@ static int read_back(ptx_ctx* c, void* dst, const void* src, size_t bytes, const
 }
 int ptx_read_accum(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->accum : nullptr, c ? (size_t)c->w * c->h * 16 : 0, "ptx_read_accum"); }
 int ptx_write_accum(ptx_ctx* c, const float* rgba, const float* m2) {
+    if (c) c->order_dirty = true;
     if (!c || !rgba) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_write_accum before ptx_resize");
     if (m2 && !c->m2) return fail(c, PTX_ERR_STATE, "ptx_write_accum with moments, but moments are not enabled");
@@ -1492,6 +1576,7 @@ int ptx_read_primary_ids(ptx_ctx* c, uint32_t* o) { return read_back(c, o, c ? c
 int ptx_read_moments(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->m2 : nullptr, c ? (size_t)c->w * c->h * 12 : 0, "ptx_read_moments"); }
 
 int ptx_debug_capture(ptx_ctx* c, uint32_t max_samples) {
+    if (c) c->order_dirty = true;
     if (!c) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_debug_capture before ptx_resize");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1511,6 +1596,7 @@ int ptx_read_debug_radiance(ptx_ctx* c, float* out, uint32_t n) {
 }
 
 int ptx_enable_moments(ptx_ctx* c, int enable) {
+    if (c) c->order_dirty = true;
     if (!c) return PTX_ERR_BAD_ARG;
     c->moments = enable != 0;
     if (c->moments && c->accum && !c->m2) {
@@ -1527,6 +1613,7 @@ void* ptx_device_moments(ptx_ctx* c) { return c ? (void*)c->m2 : nullptr; }
 
 int ptx_merge_moments(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, uint32_t n_a, const void* other_mean4,
                       const void* other_m2, uint32_t n_b, const ptx_camera* cam) {
+    if (c) c->order_dirty = true;
     if (!c || !other_mean4 || !cam) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_merge_moments before ptx_resize");
     if ((uint64_t)first_pixel + n_pixels > (uint64_t)c->w * c->h) return fail(c, PTX_ERR_BAD_ARG, "pixel range outside the frame");
@@ -1540,6 +1627,7 @@ int ptx_merge_moments(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, uint3
 }
 
 int ptx_tonemap(ptx_ctx* c, uint32_t first_pixel, uint32_t n_pixels, const ptx_camera* cam) {
+    if (c) c->order_dirty = true;
     if (!c || !cam) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_tonemap before ptx_resize");
     if ((uint64_t)first_pixel + n_pixels > (uint64_t)c->w * c->h) return fail(c, PTX_ERR_BAD_ARG, "pixel range outside the frame");
@@ -1613,6 +1701,7 @@ int ptx_comm_free(ptx_ctx* c) {
 }
 
 int ptx_merge_sample_split(ptx_ctx* c, const uint32_t* counts, const ptx_camera* cam) {
+    if (c) c->order_dirty = true;
     if (!c || !counts || !cam) return PTX_ERR_BAD_ARG;
     if (!c->comm) return fail(c, PTX_ERR_STATE, "ptx_merge_sample_split before ptx_comm_init / ptx_comm_adopt");
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_merge_sample_split before ptx_resize");
@@ -1691,6 +1780,7 @@ int ptx_merge_sample_split(ptx_ctx* c, const uint32_t* counts, const ptx_camera*
 }
 
 int ptx_assemble_tiles(ptx_ctx* c, const ptx_camera* cam) {
+    if (c) c->order_dirty = true;
     if (!c || !cam) return PTX_ERR_BAD_ARG;
     if (!c->comm) return fail(c, PTX_ERR_STATE, "ptx_assemble_tiles before ptx_comm_init / ptx_comm_adopt");
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_assemble_tiles before ptx_resize");
@@ -1720,6 +1810,7 @@ extern "C" int ptx_debug_sites(unsigned long long* out, int n_pairs) {
 // ---- GPU BVH build (bvh_build.h) ---------------------------------------------------------------------------------------
 
 int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* prim_indices_out) {
+    if (c) c->order_dirty = true;
     if (!c || !nodes_out || !n_nodes_out || (n > 0u && (!aabbs || !prim_indices_out))) return PTX_ERR_BAD_ARG;
     if (n == 0u) {  // bvh.rs:38-43
         memset(nodes_out, 0, sizeof(ptx_bvh_node));
@@ -1839,6 +1930,7 @@ int ptx_bvh_build(ptx_ctx* c, const float* aabbs, uint32_t n, ptx_bvh_node* node
 }
 
 int ptx_post_process(ptx_ctx* c, const ptx_post_params* pp) {
+    if (c) c->order_dirty = true;
     if (!c || !pp) return PTX_ERR_BAD_ARG;
     if (!c->accum) return fail(c, PTX_ERR_STATE, "ptx_post_process before ptx_resize");
     if (pp->width != c->w || pp->height != c->h) return fail(c, PTX_ERR_BAD_ARG, "post params width/height differ from the frame size");

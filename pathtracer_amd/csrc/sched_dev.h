@@ -517,8 +517,8 @@ PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate
         if (job >= P.total_jobs) return false;
         if (job_pixel(P, job, J, split)) break;
     }
-    if (split) {  // the pixel's accumulator stays in memory until the fold; its last sample owns the primary id
-        if (J.k + 1u == P.split_n) P.primary_ids[J.pix] = 0xFFFFFFFFu;
+    if (split) {  // the pixel's accumulator stays in memory until the fold; its last sample owns the primary id, staged with it
+        if (J.k + 1u == P.split_n) ((uint32_t*)&P.staging[(size_t)J.k * P.frame_pixels + J.pix])[3] = 0xFFFFFFFFu;
         return true;
     }
     float4 a = P.accum[J.pix];
@@ -541,6 +541,15 @@ PT_DEV void flush_paths(const TraceParams& P) {
         atomicAdd(&P.stats[0], (unsigned long long)__hip_atomic_load(&wave_state(P)->paths, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// The figure of a path's first hit: the "primary id" of the pixel's latest sample.  Sample-granular jobs stage it with the
+// sample (launches overlap there: the fold, which runs in launch order, writes the id), whole-pixel jobs write it directly.
+PT_DEV void write_primary(const TraceParams& P, uint32_t job, bool split, uint32_t fig) {
+    PixelJob J;
+    job_pixel(P, job, J, split);
+    if (!split) P.primary_ids[J.pix] = fig;
+    else if (J.k + 1u == P.split_n) ((uint32_t*)&P.staging[(size_t)J.k * P.frame_pixels + J.pix])[3] = fig;
+}
+
 // Ends paths and starts new ones: while `ended`, folds the finished sample's radiance into the pixel's running
 // mean (path_trace.wgsl:181, :44-49), writes a finished pixel back and claims the next, and regenerates the
 // camera ray of the next sample (random.wgsl:12-14, camera.wgsl:6-19); then starts the closest-hit traversal of
@@ -557,7 +566,8 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
             PT_SITE(36);
             job_pixel(P, job, J, true);
             V3 r = v3(dm::fmax_(rad.x, 0.0f), dm::fmax_(rad.y, 0.0f), dm::fmax_(rad.z, 0.0f));
-            P.staging[(size_t)J.k * P.frame_pixels + J.pix] = make_float4(r.x, r.y, r.z, 0.0f);
+            float* slot = (float*)&P.staging[(size_t)J.k * P.frame_pixels + J.pix];  // w: the primary hit, written at the first bounce
+            slot[0] = r.x; slot[1] = r.y; slot[2] = r.z;
             px_u[6 * 64] += 1u;  // here: paths this lane has finished
             if (!claim_pixel(P, job, false, px_f, J, true)) return LS_IDLE;
             k_next = J.k;
@@ -768,7 +778,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
                                 V3 contrib = vdivs(thr * v3p(L.le) * brdf * n_dot_l * w, pa);
                                 park[(PK_CONTRIB + 0) * 64] = contrib.x; park[(PK_CONTRIB + 1) * 64] = contrib.y; park[(PK_CONTRIB + 2) * 64] = contrib.z;
                                 n_shadow += 1u;
-                                if (first) { PixelJob J; job_pixel(P, job, J, split); if (!split || J.k + 1u == P.split_n) P.primary_ids[J.pix] = fig; }
+                                if (first) write_primary(P, job, split, fig);
                                 park[(PK_THR + 0) * 64] = thr.x; park[(PK_THR + 1) * 64] = thr.y; park[(PK_THR + 2) * 64] = thr.z;
                                 park[(PK_RAD + 0) * 64] = rad.x; park[(PK_RAD + 1) * 64] = rad.y; park[(PK_RAD + 2) * 64] = rad.z;
                                 park_u[PK_RNG * 64] = rng;
@@ -784,7 +794,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
                 }
             }
         }
-        if (first) { PixelJob J; job_pixel(P, job, J, split); if (!split || J.k + 1u == P.split_n) P.primary_ids[J.pix] = fig; }
+        if (first) write_primary(P, job, split, fig);
     } else {
         // bvh.wgsl:212-232: the plane list of the occlusion query, unless the BVH already gave an occluder.
         bool occluded = tv.slot != PT_SLOT_NONE;
