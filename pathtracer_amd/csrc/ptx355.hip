@@ -116,6 +116,7 @@ PT_DEV void trace_body(const TraceParams& P) {
                          : (xcd_remap(blockIdx.x, P.n_blocks) << 8) | threadIdx.x;
     PixelJob J;
     bool active = false;
+    const bool split = CLAIM && P.split_n > 0u;  // jobs are single samples, staged for ptx_fold_kernel (TraceParams::split_n)
     wave_claim_init(P);
     px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
     px_u[6 * 64] = 0u;            // k: samples of the current pixel finished
@@ -123,7 +124,7 @@ PT_DEV void trace_body(const TraceParams& P) {
     px_u[8 * 64] = 0xFFFFFFFFu;   // primary hit of the latest sample
     if (P.n > 0u) {
         if (CLAIM) {
-            active = claim_pixel(P, job, true, px_f, J);
+            active = claim_pixel(P, job, true, px_f, J, split);
         } else if (job_pixel(P, job, J)) {
             active = true;
             float4 a = P.accum[J.pix];
@@ -140,7 +141,7 @@ PT_DEV void trace_body(const TraceParams& P) {
     ps.ray.o = v3(0.0f, 0.0f, 0.0f);
     ps.ray.d = v3(0.0f, 0.0f, 1.0f);
     if (active) {
-        ps.rng = pcg_hash(J.px + J.py * 65536u + P.first_frame * 16777259u);  // random.wgsl:12-14
+        ps.rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + (split ? J.k : 0u)) * 16777259u);  // random.wgsl:12-14
         ps.ray = generate_ray(P.cam, ps.rng, (float)J.px, (float)J.py);
     }
 #ifdef PTX_PHASE_TIMING
@@ -161,7 +162,25 @@ PT_DEV void trace_body(const TraceParams& P) {
             if (!done && ps.bounce >= P.cam.max_bounces) done = true;
         }
         PT_TICK(4);
-        if (done) {
+        if (done && split) {
+            PT_SITE(36);
+            // the sample goes to the staging buffer, with the figure of its first hit; the fold kernel does path_trace.wgsl:181
+            float* slot = (float*)&P.staging[(size_t)J.k * P.frame_pixels + J.pix];
+            slot[0] = dm::fmax_(ps.radiance.x, 0.0f); slot[1] = dm::fmax_(ps.radiance.y, 0.0f); slot[2] = dm::fmax_(ps.radiance.z, 0.0f);
+            ((uint32_t*)slot)[3] = px_u[8 * 64];
+            px_u[7 * 64] += local_bounces;
+            local_bounces = 0u;
+            add_paths(P, 1u);
+            active = claim_pixel(P, job, false, px_f, J, true);
+            px_u[8 * 64] = 0xFFFFFFFFu;
+            if (active) {
+                ps.rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + J.k) * 16777259u);
+                ps.ray = generate_ray(P.cam, ps.rng, (float)J.px, (float)J.py);
+                ps.throughput = v3(1.0f, 1.0f, 1.0f);
+                ps.radiance = v3(0.0f, 0.0f, 0.0f);
+                ps.bounce = 0u;
+            }
+        } else if (done) {
             PT_SITE(36);
             // path_trace.wgsl:181 and :44-49
             const uint32_t k = px_u[6 * 64];
@@ -285,7 +304,7 @@ PT_DEV void sched_body(const TraceParams& P) {
     uint32_t S = LS_IDLE;
     wave_claim_init(P);
     uint32_t job = blockIdx.x * PTX_BLOCK + threadIdx.x;  // the first job of every lane; the counter starts behind them
-    const bool split = FRAC && P.split_n > 0u;  // jobs are single samples (TraceParams::split_n)
+    const bool split = P.split_n > 0u;  // jobs are single samples (TraceParams::split_n)
     if (P.n > 0u) {
         PixelJob J;
         if (claim_pixel(P, job, true, px_f, J, split)) {
@@ -704,7 +723,8 @@ struct ptx_ctx {
     uint32_t share_leaf = 4u;           // and the share of lanes at leaf primitives (one-visit-per-step mode)
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
-    bool split = true;            // scheduled fractal kernels: sample-granular jobs + fold
+    bool split = true;            // sample-granular jobs + fold where they pay (launch_trace)
+    uint32_t split_small = 2u;    // lockstep kernels: launches of up to this many samples use them
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
     // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
     struct Options {
@@ -1020,6 +1040,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
     else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || (value >= 16 && value <= 1024 && (value & (value - 1)) == 0))) o.claim_tile = (uint32_t)value; }
     else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
+    else if (k == "split_small") { if ((ok = in(0, 64))) c->split_small = (uint32_t)value; }
     else if (k == "split_chunk") { if ((ok = in(0, 0x7FFFFFFF))) o.split_chunk = (uint32_t)value; }
     else if (k == "share_walk") { if ((ok = in(0, 64))) o.shares[0] = (uint32_t)value; }
     else if (k == "share_post") { if ((ok = in(0, 64))) o.shares[1] = (uint32_t)value; }
@@ -1440,7 +1461,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Such a launch still ends on its longest paths (tens of milliseconds of a few lanes marching), and it reads nothing
     // an earlier launch writes: so every chunk traces on a stream of its own (a "flight") into a staging buffer of its own,
     // beside the tails of the chunks and calls before it, and only the folds follow one another, on the context's stream.
-    const bool split = !fixed && c->sched && frac && c->split && !c->dbg;
+    // The lockstep kernels use the same form for launches of one or two samples (the reference's own dispatch is one): the
+    // staging buffer is small there, and back-to-back dispatches hide one another's last paths (Cornell box 1080p, one sample
+    // per dispatch: 1.23 -> 0.98 ms; two: 1.76 ms, the rate of long launches).  The scheduled kernels' other scenes lose by it
+    // (teapot 4K 1.69 -> 1.77 ms, 10 M-triangle mesh 6.7 -> 7.8 ms: the fold's extra pass over the frame) and keep whole-pixel jobs.
+    const bool split = !fixed && claim && c->split && !c->dbg && ((c->sched && frac) || (!c->sched && n <= c->split_small));
     uint32_t chunk = n;
     size_t frame_pixels = 0;
     uint32_t depth = 1;
@@ -1480,7 +1505,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             continue;
         }
         P.split_n = m; P.total_jobs = P.n_blocks * 256u * m;
-        if (!c->opt.claim_tile) P.claim_tile = m >= 64u ? 256u : 128u;
+        if (!c->opt.claim_tile) P.claim_tile = !frac ? (P.n_blocks >= 16384u ? 128u : 64u) : (m >= 64u ? 256u : 128u);
         ptx_ctx::Flight& f = c->flights[c->flight_seq % depth];
         const uint32_t slot = (uint32_t)(&f - c->flights);
         if (!f.stream) {
