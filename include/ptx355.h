@@ -96,8 +96,9 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   kernel_family  -1 per scene (default), 0 lockstep kernels, 1 wave-scheduled kernels
  *   upload_path    -1 by scene size, 0 record re-layout on the host, 1 on the device
  *   claim_tile      0 per scene and launch; pixel jobs a wave reserves per claim: 1, or a power of two from 16 to 1024
- *   split_samples   1 (default) / 0: sample-granular jobs + fold (fractal scenes; short launches of the lockstep kernels)
- *   split_small     lockstep kernels: launches of up to this many samples use them (default 2, 0 = none)
+ *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)
+ *   split_small     -1 per scene (default), else: launches of up to this many samples use them, longer ones fold in the
+ *                   lane (fractal scenes on the wave-scheduled kernels always use them)
  *   split_chunk     0 = bounded by the staging buffer, else samples per chunk
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes
  *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with

@@ -248,7 +248,7 @@ PT_DEV void trace_body(const TraceParams& P) {
 // The wave-scheduled kernel body (sched_dev.h): same buffers and results as trace_body; the grid is sized to
 // the GPU, not to the frame, and lanes claim pixels as they go.
 static_assert(SC_PIXEL_FIELDS + SC_PARK_FIELDS == PT_PIXEL_FIELDS + PT_PARK_FIELDS, "both kernel families share one LDS budget");
-template <bool LDS_SCENE, bool FRAC>
+template <bool LDS_SCENE, bool FRAC, bool SAMPLES>
 PT_DEV void sched_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -304,7 +304,9 @@ PT_DEV void sched_body(const TraceParams& P) {
     uint32_t S = LS_IDLE;
     wave_claim_init(P);
     uint32_t job = blockIdx.x * PTX_BLOCK + threadIdx.x;  // the first job of every lane; the counter starts behind them
-    const bool split = P.split_n > 0u;  // jobs are single samples (TraceParams::split_n)
+    // jobs are single samples (TraceParams::split_n): the fractal kernels decide per launch, the others are compiled for one
+    // form or the other (the unused form's code cost the teapot 2.5 %)
+    const bool split = SAMPLES && (!FRAC || P.split_n > 0u);
     if (P.n > 0u) {
         PixelJob J;
         if (claim_pixel(P, job, true, px_f, J, split)) {
@@ -527,10 +529,12 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_
 #ifndef PTX_SCHED_WAVES
 #define PTX_SCHED_WAVES 4
 #endif
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel(const TraceParams P) { sched_body<false, false>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel_lds(const TraceParams P) { sched_body<true, false>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_frac(const TraceParams P) { sched_body<false, true>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_lds_frac(const TraceParams P) { sched_body<true, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel(const TraceParams P) { sched_body<false, false, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel_lds(const TraceParams P) { sched_body<true, false, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel_samples(const TraceParams P) { sched_body<false, false, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, PTX_SCHED_WAVES) ptx_sched_kernel_lds_samples(const TraceParams P) { sched_body<true, false, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_frac(const TraceParams P) { sched_body<false, true, true>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_sched_kernel_lds_frac(const TraceParams P) { sched_body<true, true, true>(P); }
 
 // Chan's parallel update of (mean, M2) with another partial result, then re-tonemap.
 extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* out_rgba8, uint32_t first, uint32_t n_pixels,
@@ -724,7 +728,7 @@ struct ptx_ctx {
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
     bool split = true;            // sample-granular jobs + fold where they pay (launch_trace)
-    uint32_t split_small = 2u;    // lockstep kernels: launches of up to this many samples use them
+    uint32_t split_upto = 0x7FFFFFFFu;  // launches of up to this many samples use them (configure(): per scene)
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
     // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
     struct Options {
@@ -735,6 +739,7 @@ struct ptx_ctx {
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
+        int64_t split_upto = -1;  // split_small: -1 per scene, else launches of up to this many samples run sample jobs (fractal scenes on the scheduled kernels always do)
         uint32_t flights = 0;     // launches of sample-granular jobs in flight at once; 0 = as many as the staging bound allows (at most PTX_FLIGHTS)
         bool verbose = false, bvh_timing = false;
     } opt;
@@ -748,12 +753,13 @@ struct ptx_ctx {
         size_t staging_n = 0;
         WaveState* wave_state = nullptr;
         size_t wave_state_n = 0;
+        StackEntry* spill = nullptr;  // deep-stack entries of its waves (scenes that need them)
+        size_t spill_waves = 0;
     };
     Flight flights[PTX_FLIGHTS];
     uint32_t flight_seq = 0;
     uint32_t* flight_counters = nullptr;  // one job counter per flight, 256 bytes apart
     hipEvent_t barrier = nullptr;         // everything enqueued on `stream` by calls other than those launches, up to the last of them
-    hipEvent_t last_traced = nullptr;     // the latest flight's trace (flights that share the deep-stack area run one after the other)
     bool order_dirty = true;              // such a call has been made since `barrier` was recorded
     const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
     size_t occ_lds = 0;
@@ -1019,6 +1025,7 @@ void ptx_destroy(ptx_ctx* c) {
         if (f.traced) (void)hipEventDestroy(f.traced);
         if (f.folded) (void)hipEventDestroy(f.folded);
         if (f.wave_state) (void)hipFree(f.wave_state);
+        if (f.spill) (void)hipFree(f.spill);
     }
     if (c->flight_counters) (void)hipFree(c->flight_counters);
     if (c->barrier) (void)hipEventDestroy(c->barrier);
@@ -1040,7 +1047,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
     else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || (value >= 16 && value <= 1024 && (value & (value - 1)) == 0))) o.claim_tile = (uint32_t)value; }
     else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
-    else if (k == "split_small") { if ((ok = in(0, 64))) c->split_small = (uint32_t)value; }
+    else if (k == "split_small") { if ((ok = in(-1, 0x7FFFFFFF))) o.split_upto = (int64_t)value; }
     else if (k == "split_chunk") { if ((ok = in(0, 0x7FFFFFFF))) o.split_chunk = (uint32_t)value; }
     else if (k == "share_walk") { if ((ok = in(0, 64))) o.shares[0] = (uint32_t)value; }
     else if (k == "share_post") { if ((ok = in(0, 64))) o.shares[1] = (uint32_t)value; }
@@ -1106,6 +1113,14 @@ static int configure(ptx_ctx* c) {
     for (int i = 0; i < 3; i++)
         if (c->opt.shares[i]) c->shares[i] = c->opt.shares[i];
     if (c->opt.shares[3]) c->share_leaf = c->opt.shares[3];
+    // Sample jobs + fold with overlapping launches against whole-pixel jobs (launch_trace), ms per sample at 1080p unless said:
+    // Cornell box 0.98 / 0.80 against 1.23 / 0.87 (1 / 128 samples per launch); all.yaml 2.04 / 1.75 against 2.67 / 2.47 (1 / 16);
+    // all.yaml + 10 M triangles 5.6 / 4.7 against 6.7 / 5.7 (1 / 16); fractals: see there; teapot 4K 1.46 / 1.37 / 1.40 / 1.43
+    // against 1.70 / 1.47 / 1.39 / 1.19 (1 / 2 / 4 / 16: a shallow tree without marched figures traces a sample in less time
+    // than it takes to stage and fold it).
+    const bool plain_mesh = c->sched && !sc.has_fractals && !marchers && sc.stack_entries < PT_DEEP_TREE;
+    c->split_upto = plain_mesh ? 2u : 0x7FFFFFFFu;
+    if (c->opt.split_upto >= 0 && !(c->sched && sc.has_fractals)) c->split_upto = (uint32_t)c->opt.split_upto;
     c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
     if (c->opt.claim_tile) c->claim_tile = c->opt.claim_tile;
     // Resident workgroups per compute unit of the kernel this scene runs: the claiming kernels' grid.
@@ -1401,7 +1416,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     P.stats = c->stats;
     const bool frac = c->sc.has_fractals != 0u;
     const size_t lds_all = trace_lds_bytes(c);
-    const TraceKernel kernel = trace_kernel_of(c);
+    TraceKernel kernel = trace_kernel_of(c);
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
@@ -1461,11 +1476,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Such a launch still ends on its longest paths (tens of milliseconds of a few lanes marching), and it reads nothing
     // an earlier launch writes: so every chunk traces on a stream of its own (a "flight") into a staging buffer of its own,
     // beside the tails of the chunks and calls before it, and only the folds follow one another, on the context's stream.
-    // The lockstep kernels use the same form for launches of one or two samples (the reference's own dispatch is one): the
-    // staging buffer is small there, and back-to-back dispatches hide one another's last paths (Cornell box 1080p, one sample
-    // per dispatch: 1.23 -> 0.98 ms; two: 1.76 ms, the rate of long launches).  The scheduled kernels' other scenes lose by it
-    // (teapot 4K 1.69 -> 1.77 ms, 10 M-triangle mesh 6.7 -> 7.8 ms: the fold's extra pass over the frame) and keep whole-pixel jobs.
-    const bool split = !fixed && claim && c->split && !c->dbg && ((c->sched && frac) || (!c->sched && n <= c->split_small));
+    // Which scenes and launch sizes use this form is measured per scene class (configure()): all but long launches of shallow
+    // meshes without marched figures.  Staging costs 16 bytes per sample, written once and read once: 4.2 GB per 128-sample
+    // launch of a 1080p frame, two such buffers in flight.
+    const bool split = !fixed && claim && c->split && !c->dbg && n <= c->split_upto;
+    if (split && c->sched && !frac) kernel = c->sc.lds_scene_bytes > 0u ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
     uint32_t chunk = n;
     size_t frame_pixels = 0;
     uint32_t depth = 1;
@@ -1513,7 +1528,8 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             HIP_TRY(c, hipEventCreateWithFlags(&f.traced, hipEventDisableTiming));
             HIP_TRY(c, hipEventCreateWithFlags(&f.folded, hipEventDisableTiming));
         }
-        if ((size_t)m * frame_pixels > f.staging_n || waves > f.wave_state_n) {  // grow: not while the flight's last launch uses them
+        const bool needs_spill = P.stack_spill != nullptr || (c->sc.lds_scene_bytes == 0u && c->sc.stack_entries > PT_LDS_STACK);
+        if ((size_t)m * frame_pixels > f.staging_n || waves > f.wave_state_n || (needs_spill && waves > f.spill_waves)) {  // grow: not while the flight's last launch uses them
             if (f.used) HIP_TRY(c, hipEventSynchronize(f.folded));
             if ((size_t)m * frame_pixels > f.staging_n) {
                 if (f.staging) { (void)hipFree(f.staging); f.staging = nullptr; f.staging_n = 0; }
@@ -1525,13 +1541,18 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
                 HIP_TRY(c, hipMalloc((void**)&f.wave_state, waves * sizeof(WaveState)));
                 f.wave_state_n = waves;
             }
+            if (needs_spill && waves > f.spill_waves) {
+                if (f.spill) { (void)hipFree(f.spill); f.spill = nullptr; f.spill_waves = 0; }
+                HIP_TRY(c, hipMalloc((void**)&f.spill, waves * (31u - PT_LDS_STACK) * 64u * sizeof(StackEntry)));
+                f.spill_waves = waves;
+            }
         }
-        // order: after whatever other calls have enqueued on the context's stream (a clear, an upload, other kernels); after the
-        // fold that read this flight's staging buffer last; after the previous flight's trace if they share the deep-stack area
+        if (needs_spill) P.stack_spill = f.spill;
+        // order: after whatever other calls have enqueued on the context's stream (a clear, an upload, other kernels) and after the
+        // fold that read this flight's staging buffer last
         if (c->order_dirty) { HIP_TRY(c, hipEventRecord(c->barrier, c->stream)); c->order_dirty = false; }
         HIP_TRY(c, hipStreamWaitEvent(f.stream, c->barrier, 0));
         if (f.used) HIP_TRY(c, hipStreamWaitEvent(f.stream, f.folded, 0));
-        if (P.stack_spill && c->last_traced) HIP_TRY(c, hipStreamWaitEvent(f.stream, c->last_traced, 0));
         P.staging = f.staging;
         P.wave_state = f.wave_state;
         P.job_counter = c->flight_counters + slot * 64u;
@@ -1539,7 +1560,6 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, f.stream, P);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(f.traced, f.stream));
-        c->last_traced = f.traced;
         HIP_TRY(c, hipStreamWaitEvent(c->stream, f.traced, 0));
         TraceParams F = P;
         F.split_n = 0u;
@@ -1987,7 +2007,9 @@ int ptx_post_process(ptx_ctx* c, const ptx_post_params* pp) {
 const char* ptx_trace_kernel_name(const ptx_ctx* c) {
     if (!c || !c->have_scene) return "";
     const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
-    if (c->sched) return lds ? (frac ? "ptx_sched_kernel_lds_frac" : "ptx_sched_kernel_lds") : (frac ? "ptx_sched_kernel_frac" : "ptx_sched_kernel");
+    const bool samples = c->split && c->split_upto > 2u;  // launches of every size run sample jobs (launch_trace)
+    if (c->sched && !frac) return lds ? (samples ? "ptx_sched_kernel_lds_samples" : "ptx_sched_kernel_lds") : (samples ? "ptx_sched_kernel_samples" : "ptx_sched_kernel");
+    if (c->sched) return lds ? "ptx_sched_kernel_lds_frac" : "ptx_sched_kernel_frac";
     return lds ? (frac ? "ptx_trace_kernel_lds_frac" : "ptx_trace_kernel_lds") : (frac ? "ptx_trace_kernel_frac" : "ptx_trace_kernel");
 }
 

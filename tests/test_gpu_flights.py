@@ -90,13 +90,14 @@ def test_resize_while_launches_are_in_flight(pt):
 
 @pytest.mark.parametrize("name", ["cornell_box", "planet", "all"])
 def test_single_sample_dispatches_of_the_lockstep_kernels_overlap_too(pt, name):
-    """One or two samples per launch run as sample jobs + fold on the lockstep kernels as well; longer launches fold in the
-    lane.  Both give the same frames, whatever the mix."""
+    """Sample jobs + fold on the lockstep kernels (and on the scheduled kernels' scenes without fractals), folding in the lane
+    for launches longer than `split_small`: the same frames, whatever the mix."""
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
     w, h = 112, 63
     ref = _frames(pt, sc, w, h, [("trace", 0, 1, 11)], kernel_family=0, split_samples=0)
     singles = _frames(pt, sc, w, h, [("trace", k, k + 1, 1) for k in range(11)], kernel_family=0)
-    mixed = _frames(pt, sc, w, h, [("trace", 0, 1, 2), ("trace", 2, 3, 5), ("trace", 7, 8, 1), ("trace", 8, 9, 2), ("trace", 10, 11, 1)], kernel_family=0)
+    mixed = _frames(pt, sc, w, h, [("trace", 0, 1, 2), ("trace", 2, 3, 5), ("trace", 7, 8, 1), ("trace", 8, 9, 2), ("trace", 10, 11, 1)], kernel_family=0,
+                    split_small=2)  # launches of up to two samples as sample jobs, the five-sample one folds in the lane
     wide = _frames(pt, sc, w, h, [("trace", 0, 1, 4), ("trace", 4, 5, 4), ("trace", 8, 9, 3)], kernel_family=0, split_small=4, flights=3)
     default = _frames(pt, sc, w, h, [("trace", k, k + 1, 1) for k in range(11)])  # the family the library picks for the scene
     assert _same(singles, ref) and _same(mixed, ref) and _same(wide, ref) and _same(default, ref)

@@ -104,7 +104,7 @@ def test_benchmark_mesh_scene_at_full_size_with_default_modes(pt):
     w, h, n = 1920, 1080, 2
     cam = sc.camera(w, h)
     sc.upload_to(pt)
-    assert pt.kernel_name() == "ptx_sched_kernel"
+    assert pt.kernel_name() == "ptx_sched_kernel_samples"  # deep tree: sample jobs + fold for launches of every size
     pt.resize(w, h)
     pt.trace_n(cam, 0, 1, n)
     a, ids, out = pt.read_accum(), pt.read_primary_ids(), pt.read_output()
