@@ -104,8 +104,9 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with
  *                  lanes at leaf primitives a state of their own, 2 walks to a leaf, tests wait as their own state
  *   grid_per_cu     0 = every resident workgroup, else workgroups per compute unit
- *   flights         launches of sample-granular jobs (fractal scenes) that may overlap: 0 = six, or as many as fit
- *                   8 GiB of staging buffers (at least two); 1 = one after the other; up to 8
+ *   flights         launches of sample-granular jobs that may overlap: 0 = per launch (fractal scenes and launches of up to
+ *                   four samples: six, or as many as fit 8 GiB of staging buffers, at least two; longer launches of other
+ *                   scenes one after the other); 1 = one after the other; up to 8
  *   verbose, bvh_timing   0 / 1: notes on stderr
  * PTX_ERR_BAD_ARG for an unknown key or a value outside its range. */
 int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value);

@@ -1496,7 +1496,12 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         // measured, fractals 1080p, one sample per launch, ms per frame with 1 / 2 / 4 / 6 / 8 in flight: 58 / 28.5 / 29 / 20.6 / 21.9
         // (HIP's default of four hardware queues per process; with GPU_MAX_HW_QUEUES=8 in the host's environment: 58 / 27.5 / 17.4 / 14.1 / 16.8)
         depth = in_flight >= PTX_FLIGHTS_DEFAULT ? PTX_FLIGHTS_DEFAULT : (in_flight < 2 ? 2u : (uint32_t)in_flight);
-        if (c->opt.flights >= 1u) depth = c->opt.flights < in_flight || c->opt.flights <= 2u ? c->opt.flights : (in_flight < 2 ? 2u : (uint32_t)in_flight);
+        // Overlap hides a launch's last paths behind the next launch: a quarter of a one-sample launch of the Cornell box, but
+        // 0.4 % of a 128-sample one (0.7 % of 8 samples of the 10 M-triangle scene); fractal launches end on tens of milliseconds
+        // of a few lanes marching whatever their length (1.9 % of 128 samples).  Longer launches of the other scenes run in turn,
+        // which also keeps every kernel's duration a quantity of its own.
+        if (!frac && n > 4u) depth = 1u;
+        if (c->opt.flights >= 1u) depth =c->opt.flights < in_flight || c->opt.flights <= 2u ? c->opt.flights : (in_flight < 2 ? 2u : (uint32_t)in_flight);
         if (!c->flight_counters) HIP_TRY(c, hipMalloc((void**)&c->flight_counters, PTX_FLIGHTS * 256));
         if (!c->barrier) HIP_TRY(c, hipEventCreateWithFlags(&c->barrier, hipEventDisableTiming));
     } else {
