@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import os
+import re
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -199,26 +200,228 @@ def load_scene(path: str, resource_root: Optional[str] = None) -> Scene:
     return Scene(cam, shapes, models)
 
 
-# --- model/obj_loader.rs -------------------------------------------------------------------------
-def _parse_mtl(path: str) -> dict:
-    mats, cur = {}, None
-    if not os.path.exists(path):
-        return mats
-    with open(path) as fh:
-        for line in fh:
-            t = line.split()
-            if not t or t[0].startswith("#"):
-                continue
-            if t[0] == "newmtl":
-                cur = {}
-                mats[t[1]] = cur
-            elif cur is not None and t[0] in ("Kd", "Ka", "Ks"):
-                cur[t[0]] = tuple(f32(x) for x in t[1:4])
-            elif cur is not None and t[0] in ("Ns", "d", "Ni"):
-                cur[t[0]] = f32(t[1])
-            elif cur is not None and t[0] == "map_Kd":
-                cur["map_Kd"] = t[1]
-    return mats
+# --- model/obj_loader.rs over tobj 4.0.3 -----------------------------------------------------------
+# tobj is a Cargo.lock pin, not part of the reference checkout: `load_obj(path, &GPU_LOAD_OPTIONS)` (triangulate,
+# single_index) is restated here from its published parser.  What the reference's scenes depend on: a numeric token
+# that Rust's `f32::from_str` / `isize::from_str` rejects fails the whole load (LoadError), and the reference then
+# logs the error and renders the scene WITHOUT that model (app/state.rs:122-140; resources/models/aelita/aelita.obj
+# has such a token); `vt` reads two values and ignores a third; a model (mesh) ends at `o` / `g` and where `usemtl`
+# changes the material; vertices are merged per (v, vt, vn) triple in first-seen order and a mesh's texcoords hold
+# only the vertices that have one; a failed MTL file leaves the model without any materials.
+class ObjLoadError(Exception):
+    pass
+
+
+_RUST_FLOAT = re.compile(r"[+-]?(?:inf|infinity|nan|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)\Z", re.IGNORECASE)
+_RUST_INT = re.compile(r"[+-]?[0-9]+\Z")
+
+
+def rust_f32(tok: str):
+    """`f32::from_str`: the decimal value rounded ONCE to binary32 (through binary64 it is rounded twice), or None."""
+    if not _RUST_FLOAT.match(tok):
+        return None
+    body = tok.lstrip("+-").lower()
+    if body in ("inf", "infinity", "nan"):
+        return f32(float(tok))
+    from fractions import Fraction
+    if tok[0] == "-":  # the sign is applied to the rounded magnitude: "-0.000000" is -0.0
+        return -rust_f32(tok[1:])
+    exact = Fraction(tok)
+    with np.errstate(over="ignore"):
+        near = f32(float(exact))
+    if not np.isfinite(near):
+        return near
+    # `near` is within one binary32 step of the exact value: pick the closest of it and its neighbours, ties to even
+    cands = [near, np.nextafter(near, f32(np.inf)), np.nextafter(near, f32(-np.inf))]
+    best = None
+    for c in cands:
+        if not np.isfinite(c):
+            continue
+        d = abs(Fraction(float(c)) - exact)
+        even = (int(np.array(c, dtype=f32).view(np.uint32)) & 1) == 0
+        if best is None or d < best[0] or (d == best[0] and even and not best[2]):
+            best = (d, c, even)
+    return best[1]
+
+
+def _rust_lines(text: str):
+    """BufRead::lines: split at "\\n" only, one trailing "\\r" dropped."""
+    return [l[:-1] if l.endswith("\r") else l for l in text.split("\n")]
+
+
+def _floatn(words, n):
+    """tobj parse_floatn: the first n of `words`, all of them valid; None when one is not or fewer than n are there."""
+    out = []
+    for w in words[:n]:
+        v = rust_f32(w)
+        if v is None:
+            return None
+        out.append(v)
+    return out if len(out) == n else None
+
+
+def _parse_mtl(path: str):
+    """tobj load_mtl: ([material dicts], {name: index}); raises ObjLoadError on what makes tobj return an error."""
+    try:
+        fh = open(path, encoding="utf-8", newline="")
+    except OSError:
+        raise ObjLoadError(f"cannot open {path}")
+    mats, index, cur = [], {}, None
+    with fh:
+        try:
+            lines = _rust_lines(fh.read())
+        except UnicodeDecodeError:
+            raise ObjLoadError(f"{path}: not UTF-8")
+    for line in lines:
+        t = line.split()
+        if not t or t[0] == "#":
+            continue
+        if t[0] == "newmtl":
+            name = line.strip()[6:].strip()
+            if not name:
+                raise ObjLoadError(f"{path}: newmtl without a name")
+            cur = {"name": name}
+            index[name] = len(mats)
+            mats.append(cur)
+        elif t[0] in ("Ka", "Kd", "Ks"):
+            v = _floatn(t[1:], 3)
+            if v is None:
+                raise ObjLoadError(f"{path}: bad {t[0]}")
+            if cur is not None:
+                cur[t[0]] = tuple(v)
+        elif t[0] in ("Ns", "Ni", "d"):
+            v = _floatn(t[1:], 1)
+            if v is None:
+                raise ObjLoadError(f"{path}: bad {t[0]}")
+            if cur is not None:
+                cur[t[0]] = v[0]
+        elif t[0] == "map_Kd":
+            tex = line.strip()[6:].strip()
+            if not tex:
+                raise ObjLoadError(f"{path}: map_Kd without a file")
+            if cur is not None:
+                cur["map_Kd"] = tex
+    return mats, index
+
+
+def tobj_load(path: str):
+    """-> (meshes, materials or None).  A mesh: {"positions": [f32...], "texcoords": [f32...], "indices": [int...],
+    "material_id": int or None}.  Raises ObjLoadError where tobj::load_obj returns Err."""
+    try:
+        fh = open(path, encoding="utf-8", newline="")
+    except OSError:
+        raise ObjLoadError(f"Failed to load OBJ: {path}")
+    with fh:
+        try:
+            lines = _rust_lines(fh.read())
+        except UnicodeDecodeError:
+            raise ObjLoadError(f"{path}: not UTF-8")
+    pos, col, tex, nrm = [], [], [], []
+    faces = []          # lists of (v, vt, vn), None where absent
+    meshes = []
+    materials, mat_index, mtl_failed = [], {}, False
+    mat_id = None
+
+    def export():
+        index_map, m = {}, {"positions": [], "texcoords": [], "indices": [], "material_id": mat_id}
+
+        def add(vert):
+            i = index_map.get(vert)
+            if i is None:
+                v, vt, vn = vert
+                if v is None or v < 0 or v * 3 + 2 >= len(pos):
+                    raise ObjLoadError(f"{path}: face vertex out of bounds")
+                m["positions"].extend(pos[v * 3:v * 3 + 3])
+                if tex and vt is not None:
+                    if vt < 0 or vt * 2 + 1 >= len(tex):
+                        raise ObjLoadError(f"{path}: face texcoord out of bounds")
+                    m["texcoords"].extend(tex[vt * 2:vt * 2 + 2])
+                if nrm and vn is not None and (vn < 0 or vn * 3 + 2 >= len(nrm)):
+                    raise ObjLoadError(f"{path}: face normal out of bounds")
+                if col and v * 3 + 2 >= len(col):
+                    raise ObjLoadError(f"{path}: face colour out of bounds")
+                i = len(index_map)
+                index_map[vert] = i
+            m["indices"].append(i)
+
+        for f in faces:
+            if len(f) == 1:
+                tris = [(f[0], f[0], f[0])]
+            elif len(f) == 2:
+                tris = [(f[0], f[1], f[1])]
+            else:
+                tris = [(f[0], f[k], f[k + 1]) for k in range(1, len(f) - 1)]
+            for tri in tris:
+                for vert in tri:
+                    add(vert)
+        faces.clear()
+        meshes.append(m)
+
+    for line in lines:
+        t = line.split()
+        if not t or t[0] == "#":
+            continue
+        if t[0] == "v":
+            v = _floatn(t[1:], 3)
+            if v is None:
+                raise ObjLoadError(f"{path}: bad vertex position")
+            pos.extend(v)
+            for w in t[4:7]:  # vertex colours, kept as far as they parse
+                c = rust_f32(w)
+                if c is None:
+                    break
+                col.append(c)
+        elif t[0] == "vt":
+            v = _floatn(t[1:], 2)
+            if v is None:
+                raise ObjLoadError(f"{path}: bad texture coordinate")
+            tex.extend(v)
+        elif t[0] == "vn":
+            v = _floatn(t[1:], 3)
+            if v is None:
+                raise ObjLoadError(f"{path}: bad normal")
+            nrm.extend(v)
+        elif t[0] in ("f", "l"):
+            sizes = (len(pos) // 3, len(tex) // 2, len(nrm) // 3)
+            face = []
+            for tok in t[1:]:
+                parts = tok.split("/")
+                if len(parts) > 3:
+                    raise ObjLoadError(f"{path}: bad face")
+                vert = [None, None, None]
+                for i, p in enumerate(parts):
+                    if p == "":
+                        continue
+                    if not _RUST_INT.match(p):
+                        raise ObjLoadError(f"{path}: bad face index")
+                    x = int(p)
+                    vert[i] = sizes[i] + x if x < 0 else x - 1  # 0 -> -1: out of bounds when used
+                face.append(tuple(vert))
+            faces.append(face)
+        elif t[0] in ("o", "g"):
+            if faces:
+                export()
+        elif t[0] == "mtllib":
+            rest = line.strip().split(" ", 1)
+            name = rest[1].strip() if len(rest) > 1 else ""
+            try:
+                mats, idx = _parse_mtl(os.path.join(os.path.dirname(path), name))
+                for k, v in idx.items():
+                    mat_index[k] = v + len(materials)
+                materials.extend(mats)
+            except ObjLoadError:
+                mtl_failed = True
+        elif t[0] == "usemtl":
+            rest = line.strip().split(" ", 1)
+            name = rest[1].strip() if len(rest) > 1 else ""
+            if not name:
+                raise ObjLoadError(f"{path}: usemtl without a name")
+            new = mat_index.get(name)
+            if new != mat_id and faces:
+                export()
+            mat_id = new
+    export()  # the last mesh
+    return meshes, (None if mtl_failed else materials)
 
 
 def _obj_material_to_pbr(om: dict, fallback: Material) -> Material:  # obj_loader.rs:178-214
@@ -242,81 +445,54 @@ def _obj_material_to_pbr(om: dict, fallback: Material) -> Material:  # obj_loade
 
 
 def load_obj(path: str, position, scale: float, default_material: Material) -> List[Shape]:
-    """obj_loader.rs:48-175 over tobj's GPU_LOAD_OPTIONS (triangulated, single index).  Supports the
-    subset the bundled models use: v / vt / f (fan-triangulated) / usemtl / mtllib with Kd-style MTL."""
-    verts, uvs = [], []
-    groups = []  # (material name or None, has_uv, [(vi, ti) * 3])
-    cur_mat, cur = None, None
-    mtl = {}
-    with open(path) as fh:
-        for line in fh:
-            t = line.split()
-            if not t or t[0].startswith("#"):
-                continue
-            if t[0] == "v":
-                verts.append((f32(t[1]), f32(t[2]), f32(t[3])))
-            elif t[0] == "vt":
-                uvs.append((f32(t[1]), f32(t[2]) if len(t) > 2 else f32(0)))
-            elif t[0] == "mtllib":
-                mtl = _parse_mtl(os.path.join(os.path.dirname(path), t[1]))
-            elif t[0] == "usemtl":
-                cur_mat, cur = t[1], None
-            elif t[0] in ("o", "g"):
-                cur = None
-            elif t[0] == "f":
-                if cur is None:
-                    cur = (cur_mat, [])
-                    groups.append(cur)
-                idx = []
-                for tok in t[1:]:
-                    p = tok.split("/")
-                    vi = int(p[0])
-                    vi = vi - 1 if vi > 0 else len(verts) + vi
-                    ti = None
-                    if len(p) > 1 and p[1]:
-                        ti = int(p[1])
-                        ti = ti - 1 if ti > 0 else len(uvs) + ti
-                    idx.append((vi, ti))
-                for k in range(1, len(idx) - 1):
-                    cur[1].extend([idx[0], idx[k], idx[k + 1]])
+    """obj_loader.rs:48-175 (`load_obj` + `build_triangles`) over `tobj_load`.  Raises ObjLoadError where the reference's
+    `load_obj` returns Err."""
+    meshes, materials = tobj_load(path)
+    if materials is None:  # resolve_materials, obj_loader.rs:61-78
+        materials = []
     sc = f32(scale)
 
-    def rv(i):  # read_vertex, obj_loader.rs:239-245
-        v = verts[i]
-        return np.array([v[0] * sc, v[1] * sc, v[2] * sc], dtype=f32)
+    def rv(positions, i):  # read_vertex, obj_loader.rs:239-245
+        return np.array([positions[i * 3] * sc, positions[i * 3 + 1] * sc, positions[i * 3 + 2] * sc], dtype=f32)
 
     bb_min = np.full(3, np.finfo(f32).max, dtype=f32)
     bb_max = np.full(3, np.finfo(f32).min, dtype=f32)
-    for _, tri in groups:
-        for vi, _ in tri:
-            v = rv(vi)
+    for m in meshes:
+        for i in m["indices"]:
+            v = rv(m["positions"], i)
             bb_min = np.minimum(bb_min, v)
             bb_max = np.maximum(bb_max, v)
     center = (bb_min + bb_max) * f32(0.5)
     offset = np.array(position, dtype=f32) - center
     name = os.path.splitext(os.path.basename(path))[0]
     out = []
-    for mat_name, tri in groups:
-        if mat_name is not None and mat_name in mtl:
-            mat = _obj_material_to_pbr(mtl[mat_name], default_material)
-            tex = mtl[mat_name].get("map_Kd")
-            if tex is not None and not os.path.exists(tex):
-                tex = os.path.join(os.path.dirname(path), tex)
+    for m in meshes:
+        tc = m["texcoords"]
+        has_uv = len(tc) > 0
+        mid = m["material_id"]
+        if mid is not None and mid < len(materials):
+            om = materials[mid]
+            mat = _obj_material_to_pbr(om, default_material)
+            tex = om.get("map_Kd")
+            if tex is not None and not os.path.exists(tex):  # resolve_texture_path, obj_loader.rs:216-237
+                cand = os.path.join(os.path.dirname(path), tex)
+                if os.path.exists(cand):
+                    tex = cand
         else:
             mat, tex = Material(**default_material.__dict__), None
-        has_uv = any(ti is not None for _, ti in tri)
-        for k in range(0, len(tri), 3):
-            vs = [rv(tri[k + j][0]) + offset for j in range(3)]
 
-            def uv(j):  # read_uv, obj_loader.rs:247-255 (V flipped)
-                ti = tri[k + j][1]
-                if not has_uv or ti is None:
-                    return (0.0, 0.0)
-                return (float(uvs[ti][0]), float(f32(1.0) - uvs[ti][1]))
+        def uv(i):  # read_uv, obj_loader.rs:247-255 (V flipped), by the merged vertex's index
+            base = i * 2
+            if not has_uv or base + 1 >= len(tc):
+                return (0.0, 0.0)
+            return (float(tc[base]), float(f32(1.0) - tc[base + 1]))
 
+        idx = m["indices"]
+        for k in range(0, len(idx) - 2, 3):
+            vs = [rv(m["positions"], idx[k + j]) + offset for j in range(3)]
             out.append(Shape(shape_type="triangle", name=name, radius=0.0, power=0.0, max_iterations=0,
                              v0=tuple(float(x) for x in vs[0]), v1=tuple(float(x) for x in vs[1]),
-                             v2=tuple(float(x) for x in vs[2]), uv0=uv(0), uv1=uv(1), uv2=uv(2),
+                             v2=tuple(float(x) for x in vs[2]), uv0=uv(idx[k]), uv1=uv(idx[k + 1]), uv2=uv(idx[k + 2]),
                              texture=tex, material=Material(**mat.__dict__)))
     return out
 
@@ -325,7 +501,10 @@ def expand_models(scene: Scene) -> List[Shape]:
     """app/state.rs:122-140: scene shapes followed by each model's triangles."""
     shapes = list(scene.shapes)
     for m in scene.models:
-        shapes.extend(load_obj(m.path, m.position, m.scale, m.material))
+        try:
+            shapes.extend(load_obj(m.path, m.position, m.scale, m.material))
+        except ObjLoadError:
+            pass  # state.rs:139: the error is logged and the scene goes on without the model
     return shapes
 
 

@@ -4,6 +4,7 @@
 #include "../../../include/pth_host.h"
 
 #include <algorithm>
+#include <cctype>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -371,33 +373,132 @@ std::string resolve_path(const std::string& scene_dir, const std::string& rel, c
     return rel;
 }
 
-// ---- OBJ (src/model/obj_loader.rs:48-255 over tobj's triangulated single-index output) ---------------------
+// ---- OBJ (src/model/obj_loader.rs:48-255 over tobj 4.0.3) ----------------------------------------------------
+// tobj is a Cargo.lock pin, not part of the reference checkout: `load_obj(path, &GPU_LOAD_OPTIONS)` (triangulate,
+// single_index) is restated from its published parser.  What the reference's scenes depend on: a numeric token that
+// Rust's f32::from_str / isize::from_str rejects fails the whole load, and the reference then logs the error and
+// renders the scene WITHOUT that model (app/state.rs:122-140; resources/models/aelita/aelita.obj has such a token);
+// `vt` reads two values and ignores a third; a mesh ends at `o` / `g` and where `usemtl` changes the material;
+// vertices are merged per (v, vt, vn) triple in first-seen order and a mesh's texcoords hold only the vertices that
+// have one; a failed MTL file leaves the model without any materials.
 struct ObjMtl { bool has_kd = false, has_ka = false, has_ks = false, has_ns = false, has_d = false, has_ni = false;
                 float kd[3], ka[3], ks[3], ns, d, ni; std::string map_kd; };
-float parse_f32(const std::string& s) { return (float)std::strtod(s.c_str(), nullptr); }
-std::map<std::string, ObjMtl> parse_mtl(const std::string& path) {
-    std::map<std::string, ObjMtl> out;
-    std::ifstream f(path);
-    std::string line, cur;
-    while (std::getline(f, line)) {
-        std::stringstream ss(line);
-        std::vector<std::string> t;
-        std::string w;
-        while (ss >> w) t.push_back(w);
-        if (t.empty() || t[0][0] == '#') continue;
-        if (t[0] == "newmtl" && t.size() > 1) { cur = t[1]; out[cur] = ObjMtl(); continue; }
-        if (cur.empty()) continue;
-        ObjMtl& m = out[cur];
-        auto v3 = [&](float* dst) { for (int i = 0; i < 3 && 1 + i < (int)t.size(); i++) dst[i] = parse_f32(t[1 + i]); };
-        if (t[0] == "Kd" && t.size() >= 4) { m.has_kd = true; v3(m.kd); }
-        else if (t[0] == "Ka" && t.size() >= 4) { m.has_ka = true; v3(m.ka); }
-        else if (t[0] == "Ks" && t.size() >= 4) { m.has_ks = true; v3(m.ks); }
-        else if (t[0] == "Ns" && t.size() >= 2) { m.has_ns = true; m.ns = parse_f32(t[1]); }
-        else if (t[0] == "d" && t.size() >= 2) { m.has_d = true; m.d = parse_f32(t[1]); }
-        else if (t[0] == "Ni" && t.size() >= 2) { m.has_ni = true; m.ni = parse_f32(t[1]); }
-        else if (t[0] == "map_Kd" && t.size() >= 2) m.map_kd = t[1];
+// f32::from_str: [sign] (inf | infinity | nan | digits[.digits] | .digits) [e [sign] digits], nothing before or after;
+// strtof rounds the decimal value once to binary32, as Rust does.
+bool rust_f32(const std::string& t, float& out) {
+    size_t i = 0, n = t.size();
+    if (i < n && (t[i] == '+' || t[i] == '-')) i++;
+    std::string body;
+    for (size_t k = i; k < n; k++) body += (char)std::tolower((unsigned char)t[k]);
+    if (body == "inf" || body == "infinity" || body == "nan") { out = std::strtof(t.c_str(), nullptr); return true; }
+    size_t d0 = i;
+    while (i < n && std::isdigit((unsigned char)t[i])) i++;
+    size_t int_digits = i - d0, frac_digits = 0;
+    if (i < n && t[i] == '.') {
+        i++;
+        size_t f0 = i;
+        while (i < n && std::isdigit((unsigned char)t[i])) i++;
+        frac_digits = i - f0;
     }
-    return out;
+    if (int_digits + frac_digits == 0) return false;
+    if (i < n && (t[i] == 'e' || t[i] == 'E')) {
+        i++;
+        if (i < n && (t[i] == '+' || t[i] == '-')) i++;
+        size_t e0 = i;
+        while (i < n && std::isdigit((unsigned char)t[i])) i++;
+        if (i == e0) return false;
+    }
+    if (i != n) return false;
+    out = std::strtof(t.c_str(), nullptr);
+    return true;
+}
+bool rust_isize(const std::string& t, long long& out) {
+    size_t i = 0, n = t.size();
+    if (i < n && (t[i] == '+' || t[i] == '-')) i++;
+    if (i == n) return false;
+    for (size_t k = i; k < n; k++) if (!std::isdigit((unsigned char)t[k])) return false;
+    out = std::strtoll(t.c_str(), nullptr, 10);
+    return true;
+}
+std::vector<std::string> split_ws(const std::string& line) {
+    std::stringstream ss(line);
+    std::vector<std::string> t;
+    std::string w;
+    while (ss >> w) t.push_back(w);
+    return t;
+}
+// tobj parse_floatn: the first n words after the keyword, all valid, exactly n of them found.
+bool floatn(const std::vector<std::string>& t, size_t first, size_t n, std::vector<float>& dst) {
+    std::vector<float> v;
+    for (size_t k = first; k < t.size() && v.size() < n; k++) {
+        float x;
+        if (!rust_f32(t[k], x)) return false;
+        v.push_back(x);
+    }
+    if (v.size() != n) return false;
+    dst.insert(dst.end(), v.begin(), v.end());
+    return true;
+}
+std::string after_keyword(const std::string& line) {  // the rest of the line after its first space, trimmed (names may hold spaces)
+    std::string s = trim(line);
+    size_t sp = s.find(' ');
+    return sp == std::string::npos ? std::string() : trim(s.substr(sp + 1));
+}
+bool valid_utf8(const std::string& s) {
+    size_t i = 0, n = s.size();
+    while (i < n) {
+        unsigned char c = (unsigned char)s[i];
+        size_t len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+        if (len == 0 || i + len > n) return false;
+        for (size_t k = 1; k < len; k++) if (((unsigned char)s[i + k] >> 6) != 2) return false;
+        i += len;
+    }
+    return true;
+}
+// tobj load_mtl.  false where tobj returns an error (the caller then drops ALL materials of the model).
+bool parse_mtl(const std::string& path, std::vector<ObjMtl>& mats, std::map<std::string, size_t>& index) {
+    std::ifstream f(path);
+    if (!f) return false;
+    std::string line;
+    ObjMtl* cur = nullptr;
+    size_t base = mats.size();
+    std::vector<ObjMtl> local;
+    std::map<std::string, size_t> local_index;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!valid_utf8(line)) return false;
+        std::vector<std::string> t = split_ws(line);
+        if (t.empty() || t[0] == "#") continue;
+        std::vector<float> v;
+        if (t[0] == "newmtl") {
+            std::string name = after_keyword(line);
+            if (name.empty()) return false;
+            local_index[name] = base + local.size();
+            local.push_back(ObjMtl());
+            cur = &local.back();
+        } else if (t[0] == "Kd" || t[0] == "Ka" || t[0] == "Ks") {
+            if (!floatn(t, 1, 3, v)) return false;
+            if (cur) {
+                if (t[0] == "Kd") { cur->has_kd = true; memcpy(cur->kd, v.data(), 12); }
+                else if (t[0] == "Ka") { cur->has_ka = true; memcpy(cur->ka, v.data(), 12); }
+                else { cur->has_ks = true; memcpy(cur->ks, v.data(), 12); }
+            }
+        } else if (t[0] == "Ns" || t[0] == "Ni" || t[0] == "d") {
+            if (!floatn(t, 1, 1, v)) return false;
+            if (cur) {
+                if (t[0] == "Ns") { cur->has_ns = true; cur->ns = v[0]; }
+                else if (t[0] == "Ni") { cur->has_ni = true; cur->ni = v[0]; }
+                else { cur->has_d = true; cur->d = v[0]; }
+            }
+        } else if (t[0] == "map_Kd") {
+            std::string tex = after_keyword(line);
+            if (tex.empty()) return false;
+            if (cur) cur->map_kd = tex;
+        }
+    }
+    mats.insert(mats.end(), local.begin(), local.end());
+    for (auto& kv : local_index) index[kv.first] = kv.second;
+    return true;
 }
 Material obj_material_to_pbr(const ObjMtl& o, const Material& fallback) {  // obj_loader.rs:178-214
     Material m = fallback;
@@ -409,71 +510,129 @@ Material obj_material_to_pbr(const ObjMtl& o, const Material& fallback) {  // ob
     if (o.has_ni && o.ni > 0.0f) m.ior = o.ni;
     return m;
 }
-bool load_obj(const std::string& path, const float* position, float scale, const Material& default_material,
-              std::vector<Shape>& out, std::string& err) {
+struct ObjVert { long long v, vt, vn; bool operator<(const ObjVert& o) const { return std::tie(v, vt, vn) < std::tie(o.v, o.vt, o.vn); } };
+struct ObjMesh { std::vector<float> positions, texcoords; std::vector<uint32_t> indices; bool has_mat = false; size_t mat = 0; };
+const long long OBJ_ABSENT = std::numeric_limits<long long>::min();
+// tobj::load_obj with GPU_LOAD_OPTIONS.  false where it returns Err.
+bool tobj_load(const std::string& path, std::vector<ObjMesh>& meshes, std::vector<ObjMtl>& materials, bool& mtl_ok, std::string& err) {
     std::ifstream f(path);
     if (!f) { err = "Failed to load OBJ: " + path; return false; }
-    std::vector<V3> verts;
-    std::vector<std::pair<float, float>> uvs;
-    struct Group { std::string mat; bool has_mat; std::vector<std::pair<int, int>> idx; };
-    std::vector<Group> groups;
-    std::map<std::string, ObjMtl> mtl;
-    std::string cur_mat;
+    std::vector<float> pos, col, tex, nrm;
+    std::vector<std::vector<ObjVert>> faces;
+    std::map<std::string, size_t> mat_index;
     bool have_mat = false;
-    int cur = -1;
+    size_t mat_id = 0;
+    mtl_ok = true;
+    auto fail_ = [&](const char* what) { err = std::string("Failed to load OBJ: ") + path + ": " + what; return false; };
+    auto export_mesh = [&]() -> bool {
+        ObjMesh m;
+        m.has_mat = have_mat; m.mat = mat_id;
+        std::map<ObjVert, uint32_t> index_map;
+        auto add = [&](const ObjVert& vert) -> bool {
+            auto it = index_map.find(vert);
+            if (it != index_map.end()) { m.indices.push_back(it->second); return true; }
+            if (vert.v == OBJ_ABSENT || vert.v < 0 || (size_t)vert.v * 3 + 2 >= pos.size()) return false;
+            m.positions.insert(m.positions.end(), pos.begin() + vert.v * 3, pos.begin() + vert.v * 3 + 3);
+            if (!tex.empty() && vert.vt != OBJ_ABSENT) {
+                if (vert.vt < 0 || (size_t)vert.vt * 2 + 1 >= tex.size()) return false;
+                m.texcoords.insert(m.texcoords.end(), tex.begin() + vert.vt * 2, tex.begin() + vert.vt * 2 + 2);
+            }
+            if (!nrm.empty() && vert.vn != OBJ_ABSENT && (vert.vn < 0 || (size_t)vert.vn * 3 + 2 >= nrm.size())) return false;
+            if (!col.empty() && (size_t)vert.v * 3 + 2 >= col.size()) return false;
+            uint32_t i = (uint32_t)index_map.size();
+            index_map[vert] = i;
+            m.indices.push_back(i);
+            return true;
+        };
+        for (auto& fc : faces) {
+            if (fc.size() == 1) { if (!add(fc[0]) || !add(fc[0]) || !add(fc[0])) return false; }
+            else if (fc.size() == 2) { if (!add(fc[0]) || !add(fc[1]) || !add(fc[1])) return false; }
+            else for (size_t k = 1; k + 1 < fc.size(); k++) if (!add(fc[0]) || !add(fc[k]) || !add(fc[k + 1])) return false;
+        }
+        faces.clear();
+        meshes.push_back(std::move(m));
+        return true;
+    };
     std::string line;
     while (std::getline(f, line)) {
-        std::stringstream ss(line);
-        std::vector<std::string> t;
-        std::string w;
-        while (ss >> w) t.push_back(w);
-        if (t.empty() || t[0][0] == '#') continue;
-        if (t[0] == "v" && t.size() >= 4) verts.push_back(mk(parse_f32(t[1]), parse_f32(t[2]), parse_f32(t[3])));
-        else if (t[0] == "vt" && t.size() >= 2) uvs.push_back({parse_f32(t[1]), t.size() > 2 ? parse_f32(t[2]) : 0.0f});
-        else if (t[0] == "mtllib" && t.size() >= 2) mtl = parse_mtl(dir_of(path) + "/" + t[1]);
-        else if (t[0] == "usemtl" && t.size() >= 2) { cur_mat = t[1]; have_mat = true; cur = -1; }
-        else if (t[0] == "o" || t[0] == "g") cur = -1;
-        else if (t[0] == "f") {
-            if (cur < 0) { groups.push_back({cur_mat, have_mat, {}}); cur = (int)groups.size() - 1; }
-            std::vector<std::pair<int, int>> idx;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!valid_utf8(line)) return fail_("not UTF-8");
+        std::vector<std::string> t = split_ws(line);
+        if (t.empty() || t[0] == "#") continue;
+        if (t[0] == "v") {
+            if (!floatn(t, 1, 3, pos)) return fail_("vertex position");
+            for (size_t k = 4; k < t.size() && k < 7; k++) {  // vertex colours, kept as far as they parse
+                float c;
+                if (!rust_f32(t[k], c)) break;
+                col.push_back(c);
+            }
+        } else if (t[0] == "vt") {
+            if (!floatn(t, 1, 2, tex)) return fail_("texture coordinate");
+        } else if (t[0] == "vn") {
+            if (!floatn(t, 1, 3, nrm)) return fail_("normal");
+        } else if (t[0] == "f" || t[0] == "l") {
+            const long long sizes[3] = {(long long)(pos.size() / 3), (long long)(tex.size() / 2), (long long)(nrm.size() / 3)};
+            std::vector<ObjVert> face;
             for (size_t k = 1; k < t.size(); k++) {
-                int vi = 0, ti = -1;
-                size_t s1 = t[k].find('/');
-                vi = std::atoi(t[k].substr(0, s1).c_str());
-                vi = vi > 0 ? vi - 1 : (int)verts.size() + vi;
-                if (s1 != std::string::npos) {
-                    size_t s2 = t[k].find('/', s1 + 1);
-                    std::string ts = t[k].substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1);
-                    if (!ts.empty()) { ti = std::atoi(ts.c_str()); ti = ti > 0 ? ti - 1 : (int)uvs.size() + ti; }
+                long long part[3] = {OBJ_ABSENT, OBJ_ABSENT, OBJ_ABSENT};
+                size_t start = 0, i = 0;
+                for (;;) {
+                    size_t slash = t[k].find('/', start);
+                    std::string p = t[k].substr(start, slash == std::string::npos ? std::string::npos : slash - start);
+                    if (i >= 3) return fail_("face");
+                    if (!p.empty()) {
+                        long long x;
+                        if (!rust_isize(p, x)) return fail_("face index");
+                        part[i] = x < 0 ? sizes[i] + x : x - 1;  // 0 -> -1: out of bounds when used
+                    }
+                    i++;
+                    if (slash == std::string::npos) break;
+                    start = slash + 1;
                 }
-                if (vi < 0 || vi >= (int)verts.size()) { err = "OBJ face index out of range in " + path; return false; }
-                idx.push_back({vi, ti});
+                face.push_back({part[0], part[1], part[2]});
             }
-            for (size_t k = 1; k + 1 < idx.size(); k++) {
-                groups[cur].idx.push_back(idx[0]);
-                groups[cur].idx.push_back(idx[k]);
-                groups[cur].idx.push_back(idx[k + 1]);
-            }
+            faces.push_back(face);
+        } else if (t[0] == "o" || t[0] == "g") {
+            if (!faces.empty() && !export_mesh()) return fail_("face vertex out of bounds");
+        } else if (t[0] == "mtllib") {
+            if (!parse_mtl(dir_of(path) + "/" + after_keyword(line), materials, mat_index)) mtl_ok = false;
+        } else if (t[0] == "usemtl") {
+            std::string name = after_keyword(line);
+            if (name.empty()) return fail_("usemtl without a name");
+            auto it = mat_index.find(name);
+            bool new_have = it != mat_index.end();
+            size_t new_id = new_have ? it->second : 0;
+            if ((new_have != have_mat || (new_have && new_id != mat_id)) && !faces.empty() && !export_mesh()) return fail_("face vertex out of bounds");
+            have_mat = new_have; mat_id = new_id;
         }
     }
-    auto rv = [&](int i) { return mk(verts[i].x * scale, verts[i].y * scale, verts[i].z * scale); };  // obj_loader.rs:239-245
+    if (!export_mesh()) return fail_("face vertex out of bounds");
+    return true;
+}
+bool load_obj(const std::string& path, const float* position, float scale, const Material& default_material,
+              std::vector<Shape>& out, std::string& err) {
+    std::vector<ObjMesh> meshes;
+    std::vector<ObjMtl> materials;
+    bool mtl_ok = true;
+    if (!tobj_load(path, meshes, materials, mtl_ok, err)) return false;
+    if (!mtl_ok) materials.clear();  // resolve_materials, obj_loader.rs:61-78
+    auto rv = [&](const ObjMesh& m, uint32_t i) { return mk(m.positions[i * 3] * scale, m.positions[i * 3 + 1] * scale, m.positions[i * 3 + 2] * scale); };  // obj_loader.rs:239-245
     float fmax_ = std::numeric_limits<float>::max();
     V3 bb_min = mk(fmax_, fmax_, fmax_), bb_max = mk(-fmax_, -fmax_, -fmax_);
-    for (auto& g : groups)
-        for (auto& vi : g.idx) { V3 v = rv(vi.first); bb_min = vmin(bb_min, v); bb_max = vmax(bb_max, v); }
+    for (auto& m : meshes)
+        for (uint32_t i : m.indices) { V3 v = rv(m, i); bb_min = vmin(bb_min, v); bb_max = vmax(bb_max, v); }
     V3 ctr = (bb_min + bb_max) * 0.5f;
     V3 offset = mk(position) - ctr;
-    for (auto& g : groups) {
+    for (auto& m : meshes) {
         Material mat = default_material;
         std::string tex;
-        if (g.has_mat && mtl.count(g.mat)) {
-            mat = obj_material_to_pbr(mtl[g.mat], default_material);
-            tex = mtl[g.mat].map_kd;
-            if (!tex.empty() && !file_exists(tex)) tex = dir_of(path) + "/" + tex;
+        if (m.has_mat && m.mat < materials.size()) {
+            mat = obj_material_to_pbr(materials[m.mat], default_material);
+            tex = materials[m.mat].map_kd;
+            if (!tex.empty() && !file_exists(tex) && file_exists(dir_of(path) + "/" + tex)) tex = dir_of(path) + "/" + tex;  // resolve_texture_path, obj_loader.rs:216-237
         }
-        bool has_uv = false;
-        for (auto& vi : g.idx) if (vi.second >= 0) has_uv = true;
-        for (size_t k = 0; k + 2 < g.idx.size(); k += 3) {
+        const bool has_uv = !m.texcoords.empty();
+        for (size_t k = 0; k + 2 < m.indices.size(); k += 3) {
             Shape s;
             s.type = 7;
             s.radius = 0.0f;
@@ -482,10 +641,11 @@ bool load_obj(const std::string& path, const float* position, float scale, const
             float* vs[3] = {s.v0, s.v1, s.v2};
             float* us[3] = {s.uv0, s.uv1, s.uv2};
             for (int j = 0; j < 3; j++) {
-                V3 v = rv(g.idx[k + j].first) + offset;
+                const uint32_t i = m.indices[k + j];
+                V3 v = rv(m, i) + offset;
                 vs[j][0] = v.x; vs[j][1] = v.y; vs[j][2] = v.z;
-                int ti = g.idx[k + j].second;
-                if (has_uv && ti >= 0 && ti < (int)uvs.size()) { us[j][0] = uvs[ti].first; us[j][1] = 1.0f - uvs[ti].second; }  // V flip
+                const size_t base = (size_t)i * 2;  // read_uv, obj_loader.rs:247-255: by the merged vertex's index, V flipped
+                if (has_uv && base + 1 < m.texcoords.size()) { us[j][0] = m.texcoords[base]; us[j][1] = 1.0f - m.texcoords[base + 1]; }
             }
             s.texture = tex;
             s.material = mat;

@@ -1,5 +1,6 @@
 """CPU tier: the product's C++ host library (include/pth_host.h) against the independent numpy
 restatement in oracle/host_prep.py — every scene buffer and the camera uniform, bit for bit."""
+import glob
 import os
 
 import numpy as np
@@ -7,7 +8,7 @@ import pytest
 
 from oracle import host_prep as hp
 from pathtracer_amd import host
-from util import REFERENCE, fixture
+from util import REFERENCE, SCENE_DIR, fixture
 
 KEYS = ["figs", "mats", "nodes", "prims", "lights", "infinite", "tex_pixels", "tex_infos"]
 
@@ -17,7 +18,7 @@ def _assert_same(b: dict, sb: hp.SceneBuffers):
         assert b[k].tobytes() == getattr(sb, k).tobytes(), k
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "teapot", "fractals", "all", "planet"])
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(SCENE_DIR, "*.npz"))))
 def test_fixture_build_matches_numpy_restatement(name):
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
     sb = hp.prepare_fixture(fixture(name))
@@ -27,7 +28,7 @@ def test_fixture_build_matches_numpy_restatement(name):
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not mounted")
-@pytest.mark.parametrize("name", ["cornell_box", "teapot", "fractals", "all", "planet", "playground", "rings", "demo"])
+@pytest.mark.parametrize("name", ["cornell_box", "teapot", "fractals", "all", "planet", "playground", "rings", "demo"])  # all 30: tests/test_obj_loader.py
 def test_yaml_ingest_matches_numpy_restatement(name):
     path = f"{REFERENCE}/resources/scenes/{name}.yaml"
     sc = host.Scene.load(path, REFERENCE).build()

@@ -1,8 +1,9 @@
 """Writes data/scenes/<name>.npz from the reference's scene files (run in the build container, where the
 reference checkout is mounted; the GPU box never sees it).  A fixture is DATA: the authored shape list
 (after OBJ expansion) in figure/material record containers, the camera block and decoded textures.
-teapot.yaml's 1.9 MB wood.jpg is replaced by a 64x64 procedural texture (its plane's base_color is 0, so
-the texture cannot change any pixel; the fetch path is still exercised).
+Textures larger than 128x128 (teapot.yaml's 1.9 MB wood.jpg, the planets' maps, the skyboxes) are replaced by a 64x64
+procedural texture: the renders of the fixtures are compared with the oracle's renders of the same fixtures, not with
+images of the reference.  A model whose OBJ file tobj would refuse (aelita.obj) is left out, as the reference leaves it out.
 
 Usage: python tools/make_scene_fixtures.py [/root/reference]
 """
@@ -16,7 +17,10 @@ sys.path.insert(0, ROOT)
 from oracle import host_prep as hp  # noqa: E402  (fixture generation is test tooling)
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-SCENES = ["cornell_box", "teapot", "fractals", "all", "planet", "textures"]
+import glob  # noqa: E402
+
+# every scene file the reference ships (30): the four benchmark scenes, one scene per primitive type, the textured and the model scenes
+SCENES = sorted(os.path.basename(p)[:-5] for p in glob.glob(f"{REF}/resources/scenes/*.yaml"))
 
 
 def authored_records(shapes):
