@@ -186,3 +186,15 @@ def test_division_contract_reciprocal_flushes_subnormals_and_is_correctly_rounde
     got = orc.math_op("rcp", np.array([c[0] for c in cases], dtype=np.float32))
     assert same_bits(got, np.array([c[1] for c in cases], dtype=np.float32)) == 0
     assert np.isnan(orc.math_op("rcp", np.array([np.nan], dtype=np.float32))[0])
+
+
+def test_oracle_reproduces_the_digests_of_every_reference_scene():
+    """All 30 scene files of the reference as fixtures: counters and SHA-256 of ids / mean / M2 / rgba8 (tests/golden/make_golden.py)."""
+    import json
+    import sys
+    sys.path.insert(0, GOLDEN_DIR)
+    from make_golden import scene_digest
+    want = json.load(open(os.path.join(GOLDEN_DIR, "scene_digests.json")))
+    assert len(want) == 30
+    for name, d in want.items():
+        assert scene_digest(fixture(name)) == d, name
