@@ -18,6 +18,37 @@ def pt():
     t.close()
 
 
+def test_reference_plumbing_configuration_whole_frame(pt):
+    """cornell_box.yaml 512x512, 16 samples — the configuration the reference itself would run headless — dispatched as the
+    reference dispatches it (one sample per call, frame_index = sample index, sample_count counting from 1) through the
+    reference's frame loop restated on the host, the WHOLE frame against the oracle: ids, mean, M2, rgba8, counters; then the
+    same 16 frames in one batched launch with per-sample radiance."""
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h, n = 512, 512, 16
+    sb = hp.prepare_fixture(fixture("cornell_box"))
+    ocam = hp.camera_to_gpu(sb.camera, w, h)
+    ref = orc.render(orc.OracleScene(sb), ocam, n, want_radiance=True, want_m2=True, counters=True)
+    pt.enable_moments(True)
+    loop = host.FrameLoop(sc, pt, w, h)
+    for _ in range(n):
+        loop.render_frame()
+    c = ref["counters"]
+    for batched in (False, True):
+        if batched:
+            pt.clear()
+            pt.debug_capture(n)
+            pt.trace_n(sc.camera(w, h), 0, 1, n)
+            assert same_bits(pt.read_debug_radiance(n), ref["radiance"]) == 0
+            pt.debug_capture(0)
+        assert (pt.read_primary_ids() == ref["primary_id"]).all()
+        assert same_bits(pt.read_accum(), ref["accum"]) == 0
+        assert same_bits(pt.read_moments(), ref["m2"]) == 0
+        assert (pt.read_output() == ref["rgba8"]).all()
+        st = pt.stats()
+        assert (st["paths"], st["bounces"], st["shadow_rays"]) == (c["paths"], c["bounces"], c["shadow_rays"])
+    pt.enable_moments(False)
+
+
 def test_cornell_1080p_properties(pt):
     sc = host.Scene.from_fixture(fixture("cornell_box")).build()
     w, h, n = 1920, 1080, 32
