@@ -319,8 +319,9 @@ PT_DEV void sched_body(const TraceParams& P) {
     // The scheduler.  A state is served when at least 1/share of the wave's live lanes wait in it, WALK before
     // POST before the fullest marcher; a marcher then keeps stepping while three quarters of its lanes are
     // still marching.  When no state reaches its share the fullest one is served, so every round makes
-    // progress.  The shares are set per scene class by the host (measured): meshes walk whenever any lane can
-    // (64, 2, 4), meshes with ray-marched figures 8, 2, 4, fractal scenes 64, 8, 4, small scenes with a Moebius strip 4, 2, 4.
+    // progress.  The shares are set per scene class by the host (measured): meshes, with or without ray-marched figures,
+    // 8, 2, 4 (teapot 4K: 7 110 -> 7 900 Mpaths/s against 64, 2, 4, which was best before the per-wave claims), fractal scenes 64, 8, 4, small scenes with a Moebius strip 1, 2, 8
+    // (with sample jobs: the fullest state unless half the lanes stand in POST or an eighth in a marcher; all.yaml 1 174 -> 1 340 Mpaths/s).
     for (;;) {
         uint32_t pop[LS_COUNT];
         uint32_t live = 0u, fullest = LS_IDLE, fullest_n = 0u, march = LS_IDLE, march_n = 0u;
@@ -1099,7 +1100,7 @@ static int configure(ptx_ctx* c) {
     const uint32_t type_mask = c->type_mask;
     const uint32_t fractal_bits = (1u << FIG_MANDELBULB) | (1u << FIG_JULIA);
     c->sched = pick_sched(sc, type_mask, c->opt.family);
-    const uint32_t mesh[3] = {64u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {4u, 2u, 4u};
+    const uint32_t mesh[3] = {8u, 2u, 4u}, mixed[3] = {8u, 2u, 4u}, fractal[3] = {64u, 8u, 4u}, small[3] = {1u, 2u, 8u};
     // deep trees (one node visit per step, lanes at leaf primitives served as a state of their own): walk, post, march, leaf
     const uint32_t deep_mesh[4] = {12u, 2u, 4u, 4u}, deep_mixed[4] = {4u, 2u, 16u, 6u};
     const bool marchers = (type_mask & ((1u << FIG_TORUS) | (1u << FIG_MEBIUS) | fractal_bits)) != 0u;

@@ -12,6 +12,9 @@ quads = int(sys.argv[1]) if len(sys.argv) > 1 else 2236
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 settings = sys.argv[3:] or ["8,2,4,64", "8,2,4,8", "8,2,4,4", "8,2,4,3", "8,2,4,2", "8,2,4,1", "64,2,4,4", "64,2,4,2", "16,2,4,3", "8,4,4,3"]
 pt = PathTracer(0)
+for kv in filter(None, os.environ.get("SWEEP_OPTS", "").split(",")):  # further ptx_set_option settings, e.g. SWEEP_OPTS=claim_tile=128
+    k, v = kv.split("=")
+    pt.set_option(k, int(v))
 sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", os.environ.get("SWEEP_SCENE", "all") + ".npz"))
 if quads:
     sc.append_heightfield(quads)
