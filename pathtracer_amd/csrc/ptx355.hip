@@ -307,6 +307,7 @@ PT_DEV void sched_body(const TraceParams& P) {
     // jobs are single samples (TraceParams::split_n): the fractal kernels decide per launch, the others are compiled for one
     // form or the other (the unused form's code cost the teapot 2.5 %)
     const bool split = SAMPLES && (!FRAC || P.split_n > 0u);
+    constexpr bool PARK_JOB = SAMPLES && !FRAC;
     if (P.n > 0u) {
         PixelJob J;
         if (claim_pixel(P, job, true, px_f, J, split)) {
@@ -316,6 +317,7 @@ PT_DEV void sched_body(const TraceParams& P) {
             S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u, split);
         }
     }
+    if (PARK_JOB) { px_u[0 * 64] = job; px_u[1 * 64] = 0u; }
     // The scheduler.  A state is served when at least 1/share of the wave's live lanes wait in it, WALK before
     // POST before the fullest marcher; a marcher then keeps stepping while three quarters of its lanes are
     // still marching.  When no state reaches its share the fullest one is served, so every round makes
@@ -363,7 +365,18 @@ PT_DEV void sched_body(const TraceParams& P) {
         } else if (pick == LS_LEAF) {
             if (S == LS_LEAF) S = leaf_step<FRAC>(sc, tv, P.cam.fractal_march_steps, single, frac);
         } else if (pick == LS_POST) {
-            if (S == LS_POST) S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
+            if (S == LS_POST) {
+                if (PARK_JOB) {
+                    // sample jobs of the non-fractal kernels: the lane's job number and its tally of occlusion queries are read
+                    // only here, so they wait in the LDS slots the running mean does not use in this job form instead of in
+                    // registers (the kernel then fits four waves per SIMD without scratch)
+                    uint32_t job_ = px_u[0 * 64], shadow_ = px_u[1 * 64];
+                    S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job_, shadow_, split);
+                    px_u[0 * 64] = job_; px_u[1 * 64] = shadow_;
+                } else {
+                    S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
+                }
+            }
         } else {
             const uint32_t n0 = pop[pick];
             if (FRAC && pick >= (uint32_t)LS_MANDEL) {
@@ -482,6 +495,7 @@ PT_DEV void sched_body(const TraceParams& P) {
         }
     }
     const uint32_t n_bounce = px_u[7 * 64];
+    if (PARK_JOB) n_shadow = px_u[1 * 64];
     uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
     const uint32_t sp = split ? wave_sum(px_u[6 * 64]) : 0u;
     if (!split) flush_paths(P);
