@@ -256,7 +256,13 @@ PT_DEV void sched_body(const TraceParams& P) {
     st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
     st.glb = walk_stack_glb(P.stack_spill, blockIdx.x * PTX_WAVES_PER_BLOCK + wave, lane);
     st.nl = P.sc.lds_stack_entries;
-    constexpr uint32_t kFields = SC_PIXEL_FIELDS + SC_PARK_FIELDS + (FRAC ? SC_FRAC_FIELDS : 0u);  // per-lane LDS slots
+    // Sample jobs of the non-fractal kernels keep no running mean in the lane: pixel slots 0-3 do not exist there (the slot
+    // base is shifted, so that the remaining slots keep their numbers: 4 job number, 5 occlusion queries, 6 paths finished,
+    // 7 path-bounces), and the four slots go to the traversal stack instead -- two more entries in LDS for the global-scene
+    // kernel (launch_trace sets lds_stack_entries), within the same 40 slots per lane.
+    constexpr bool PARK_JOB = SAMPLES && !FRAC;
+    constexpr uint32_t kNoSlots = PARK_JOB ? SC_SAMPLE_JOB_FREE : 0u;
+    constexpr uint32_t kFields = SC_PIXEL_FIELDS - kNoSlots + SC_PARK_FIELDS + (FRAC ? SC_FRAC_FIELDS : 0u);  // per-lane LDS slots
     float* fields = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u);
     DScene sc = P.sc;
     if (LDS_SCENE) {
@@ -276,11 +282,11 @@ PT_DEV void sched_body(const TraceParams& P) {
         sc.negs = (const DNeg*)stage(P.sc.negs, P.sc.nneg * (uint32_t)sizeof(DNeg));
         __syncthreads();
     }
-    float* px_f = fields + (size_t)wave * kFields * 64u + lane;
+    float* px_f = fields + (size_t)wave * kFields * 64u + lane - kNoSlots * 64u;
     uint32_t* px_u = (uint32_t*)px_f;
     float* park = px_f + SC_PIXEL_FIELDS * 64u;
     float* frac = park + SC_PARK_FIELDS * 64u;  // FRAC kernels only
-    px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
+    if (!PARK_JOB) { px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f; }
     px_u[6 * 64] = 0u;  // samples of the current pixel finished
     px_u[7 * 64] = 0u;  // path-bounces, all pixels of this lane
     // FRAC: which lanes of each wave stand in an estimator, i.e. own a fractal march (republished every scheduling round),
@@ -307,7 +313,6 @@ PT_DEV void sched_body(const TraceParams& P) {
     // jobs are single samples (TraceParams::split_n): the fractal kernels decide per launch, the others are compiled for one
     // form or the other (the unused form's code cost the teapot 2.5 %)
     const bool split = SAMPLES && (!FRAC || P.split_n > 0u);
-    constexpr bool PARK_JOB = SAMPLES && !FRAC;
     if (P.n > 0u) {
         PixelJob J;
         if (claim_pixel(P, job, true, px_f, J, split)) {
@@ -317,7 +322,7 @@ PT_DEV void sched_body(const TraceParams& P) {
             S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u, split);
         }
     }
-    if (PARK_JOB) { px_u[0 * 64] = job; px_u[1 * 64] = 0u; }
+    if (PARK_JOB) { px_u[4 * 64] = job; px_u[5 * 64] = 0u; }
     // The scheduler.  A state is served when at least 1/share of the wave's live lanes wait in it, WALK before
     // POST before the fullest marcher; a marcher then keeps stepping while three quarters of its lanes are
     // still marching.  When no state reaches its share the fullest one is served, so every round makes
@@ -368,11 +373,11 @@ PT_DEV void sched_body(const TraceParams& P) {
             if (S == LS_POST) {
                 if (PARK_JOB) {
                     // sample jobs of the non-fractal kernels: the lane's job number and its tally of occlusion queries are read
-                    // only here, so they wait in the LDS slots the running mean does not use in this job form instead of in
-                    // registers (the kernel then fits four waves per SIMD without scratch)
-                    uint32_t job_ = px_u[0 * 64], shadow_ = px_u[1 * 64];
+                    // only here, so they wait in LDS slots instead of in registers (the kernel then fits four waves per SIMD
+                    // without scratch)
+                    uint32_t job_ = px_u[4 * 64], shadow_ = px_u[5 * 64];
                     S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job_, shadow_, split);
-                    px_u[0 * 64] = job_; px_u[1 * 64] = shadow_;
+                    px_u[4 * 64] = job_; px_u[5 * 64] = shadow_;
                 } else {
                     S = post_step<FRAC>(sc, P, tv, park, frac, px_f, job, n_shadow, split);
                 }
@@ -495,7 +500,7 @@ PT_DEV void sched_body(const TraceParams& P) {
         }
     }
     const uint32_t n_bounce = px_u[7 * 64];
-    if (PARK_JOB) n_shadow = px_u[1 * 64];
+    if (PARK_JOB) n_shadow = px_u[5 * 64];
     uint32_t sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
     const uint32_t sp = split ? wave_sum(px_u[6 * 64]) : 0u;
     if (!split) flush_paths(P);
@@ -1495,7 +1500,14 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // meshes without marched figures.  Staging costs 16 bytes per sample, written once and read once: 4.2 GB per 128-sample
     // launch of a 1080p frame, two such buffers in flight.
     const bool split = !fixed && claim && c->split && !c->dbg && n <= c->split_upto;
-    if (split && c->sched && !frac) kernel = c->sc.lds_scene_bytes > 0u ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
+    if (split && c->sched && !frac) {
+        kernel = c->sc.lds_scene_bytes > 0u ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
+        // the slots of the running mean, which sample jobs do not keep, hold two more stack entries (same LDS bytes: sched_body)
+        if (c->sc.lds_scene_bytes == 0u && c->sc.stack_entries > PT_LDS_STACK) {
+            const uint32_t more = PT_LDS_STACK + SC_SAMPLE_JOB_FREE / 2u;
+            P.sc.lds_stack_entries = c->sc.stack_entries < more ? c->sc.stack_entries : more;
+        }
+    }
     uint32_t chunk = n;
     size_t frame_pixels = 0;
     uint32_t depth = 1;

@@ -58,6 +58,7 @@ enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS
 
 // Per-lane LDS slots (lane-interleaved: slot f of this lane at base[f * 64]).
 #define SC_PIXEL_FIELDS 8u   // mean xyz, M2 xyz, samples finished, path-bounce tally
+#define SC_SAMPLE_JOB_FREE 4u  // of those, slots 0-3 that sample jobs of the non-fractal kernels do not have (sched_body)
 #define SC_PARK_FIELDS 24u   // below
 enum : uint32_t {
     PK_HPOS = 0, PK_N = 3, PK_BASE = 6, PK_FIG = 9, PK_CONTRIB = 10,  // inputs of the BSDF step, parked across the occlusion query
