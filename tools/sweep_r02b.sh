@@ -1,9 +1,7 @@
 #!/bin/bash
-# Shares of the fractal scenes (GPU box).
+# Teapot 4K: sample jobs + fold against whole-pixel jobs per launch length, with the mesh shares 8/2/4 (GPU box).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-echo "== fractals 1080p 32 spp"
-SWEEP_SCENE=fractals timeout -k 10 600 python3 tools/sweep_leaf.py 0 32 64,8,4,4 64,4,4,4 64,16,4,4 16,8,4,4 8,8,4,4 64,8,2,4 64,8,8,4 64,8,16,4 32,8,4,4 64,12,4,4 64,8,4,4 2>/dev/null | grep shares || exit 1
-for sc in julia mandelbulb; do
-  echo "== $sc 1080p 16 spp"
-  SWEEP_SCENE=$sc timeout -k 10 600 python3 tools/sweep_leaf.py 0 16 64,8,4,4 16,8,4,4 64,4,4,4 64,8,8,4 2>/dev/null | grep shares || exit 1
+for ss in 0 64; do
+  echo "== teapot 4K split_small=$ss (0: whole-pixel jobs always; 64: sample jobs up to 64 samples per launch)"
+  PROBE_OPTS="split_small=$ss" PROBE_N=1,2,4,8,16 timeout -k 10 300 python3 tools/perf_probe.py teapot 2>/dev/null | grep "n=" | cut -c1-80 || exit 1
 done
