@@ -245,6 +245,250 @@ PT_DEV void trace_body(const TraceParams& P) {
     }
 }
 
+// Lockstep kernel over SORTED PATH POOLS (sample-granular jobs, scenes staged in LDS, long launches).
+//
+// In trace_body a wave's lanes hold unrelated rays after the first bounce: on the Cornell box the closest-hit query of a wave
+// visits every leaf for a few lanes each.  The same query over the same rays runs 1.95 times as fast when each wave's rays
+// share the leaf boxes they enter and the order they enter them in (tools/coherence_probe.py).  Sorting a workgroup's 256
+// paths before every bounce gets part of that but stalls on a barrier per bounce (measured: fewer instructions, lower issue
+// rate).  Here a workgroup owns a POOL of pool_m paths (4096: sixteen per lane) in global memory, two buffers of 64-byte
+// records, and works in rounds:
+//   top-up    the pool is refilled to pool_m with new paths -- ONE device atomic per workgroup and round reserves the jobs,
+//             every lane generates camera rays (the code that ends and starts paths, which trace_body runs for 14 of 64 lanes
+//             after every bounce, runs here for all lanes a few times per round);
+//   sort      counting sort of the pool's keys (regroup_key: which key boxes the ray's box test hits, in which order) through
+//             an LDS histogram: the order the buffer is traced in;
+//   trace     waves take chunks of 64 paths of the sorted order from an LDS counter (a wave that is done early takes the next
+//             chunk: the waves of a workgroup finish a round within one chunk of each other), run ONE bounce for each path,
+//             stage finished samples, and append the paths that go on, with the key of their new ray, to the other buffer.
+// One barrier sequence per ROUND (sixteen wave-bounces per wave), not per bounce.  A path's arithmetic is the lockstep
+// kernel's whichever lane runs it and samples are folded in order by ptx_fold_kernel: bit-identical frames.
+#define RG_BINS 128u
+PT_DEV uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= (uint32_t)off) v += u;
+    }
+    return v;
+}
+PT_DEV void lds_settle() { __builtin_amdgcn_s_waitcnt(0xC07F); }  // this wave's LDS operations have been performed
+PT_DEV void wg_sync() { lds_settle(); __syncthreads(); }
+// kbox: four boxes {min xyz, -, max xyz, -}; valid: bit i set when box i exists (wave-uniform).
+PT_DEV uint32_t regroup_key(const float* kbox, uint32_t valid, const Ray& ray) {
+    const V3 inv = vrcp(ray.d);
+    float t[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+        t[i] = PT_MAX_T;
+        if (valid & (1u << i)) t[i] = intersect_aabb(ray.o, inv, kbox + i * 8u, kbox + i * 8u + 4u);
+    }
+    uint32_t key = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) key |= t[i] < PT_MAX_T ? 8u << i : 0u;
+    key |= t[0] < t[1] ? 1u : 0u;
+    key |= t[2] < t[3] ? 2u : 0u;
+    key |= dm::fmin_(t[0], t[1]) < dm::fmin_(t[2], t[3]) ? 4u : 0u;
+    return key;  // < RG_BINS
+}
+PT_DEV void pool_store(PoolPath* dst, const PathState& ps, uint32_t job, uint32_t primary) {
+    float4* q = (float4*)dst;
+    q[0] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, __uint_as_float(ps.rng));
+    q[1] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(ps.bounce));
+    q[2] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, __uint_as_float(job));
+    q[3] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, __uint_as_float(primary));
+}
+template <bool FRAC>
+PT_DEV void sorted_body(const TraceParams& P) {
+    extern __shared__ StackEntry lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t kSlots = PT_PIXEL_FIELDS + PT_PARK_FIELDS;
+    WalkStack st;
+    st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
+    st.glb = nullptr;
+    st.nl = P.sc.lds_stack_entries;
+    float* fields = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u);
+    DScene sc = P.sc;
+    {
+        char* base = (char*)(fields + (size_t)PTX_WAVES_PER_BLOCK * kSlots * 64u);
+        uint32_t off = 0;
+        auto stage = [&](const void* src, uint32_t bytes) -> void* {
+            void* dst = base + off;
+            copy_to_lds(dst, src, bytes);
+            off += bytes;
+            return dst;
+        };
+        sc.prims = (const DPrim*)stage(P.sc.prims, P.sc.nprim * (uint32_t)sizeof(DPrim));
+        sc.inf = (const DPrim*)stage(P.sc.inf, P.sc.ninf * (uint32_t)sizeof(DPrim));
+        sc.pairs = (const DNodePair*)stage(P.sc.pairs, P.sc.npair * (uint32_t)sizeof(DNodePair));
+        sc.shade = (const DShade*)stage(P.sc.shade, P.sc.nfig * (uint32_t)sizeof(DShade));
+        sc.lights = (const DLight*)stage(P.sc.lights, P.sc.nlight * (uint32_t)sizeof(DLight));
+        sc.negs = (const DNeg*)stage(P.sc.negs, P.sc.nneg * (uint32_t)sizeof(DNeg));
+    }
+    // Sample jobs keep no running mean in the lane: the per-pixel slots 0-5 of every wave are free.  Wave 0's hold the
+    // histogram, the bins' offsets and the round's counters; wave 1's the key boxes.
+    uint32_t* hist = (uint32_t*)fields;
+    uint32_t* offs = hist + RG_BINS;
+    uint32_t* cv = offs + RG_BINS;  // 0 paths in the current buffer, 1 paths appended to the other, 2 next chunk, 3 first reserved job, 4 no job left, 5 jobs reserved this round
+    float* kbox = fields + (size_t)kSlots * 64u;
+    float* px_f = fields + (size_t)wave * kSlots * 64u + lane;
+    float* park = px_f + PT_PIXEL_FIELDS * 64u;
+    const uint32_t M = P.pool_m;
+    PoolPath* const buf0 = P.pool + (size_t)blockIdx.x * 2u * M;
+    uint32_t* const keys0 = P.pool_keys + (size_t)blockIdx.x * 2u * M;
+    uint32_t* const order = P.pool_order + (size_t)blockIdx.x * M;
+    if (threadIdx.x < 8u) cv[threadIdx.x] = 0u;
+    if (threadIdx.x == 0u) {
+        // the key boxes: the children of the root's children (a child that is a leaf stands for itself)
+        uint32_t valid = 0u;
+        auto put = [&](uint32_t i, const float* mn, const float* mx) {
+            for (int a = 0; a < 3; a++) { kbox[i * 8u + a] = mn[a]; kbox[i * 8u + 4u + a] = mx[a]; }
+            valid |= 1u << i;
+        };
+        if (P.sc.nprim > 0u && (P.sc.root_ref >> PT_REF_BITS) == 0u) {
+            const DNodePair& r = P.sc.pairs[P.sc.root_ref & PT_REF_MASK];
+            if (r.lcnt == 0u) { const DNodePair& q = P.sc.pairs[r.lref]; put(0u, q.lmin, q.lmax); put(1u, q.rmin, q.rmax); }
+            else put(0u, r.lmin, r.lmax);
+            if (r.rcnt == 0u) { const DNodePair& q = P.sc.pairs[r.rref]; put(2u, q.lmin, q.lmax); put(3u, q.rmin, q.rmax); }
+            else put(2u, r.rmin, r.rmax);
+        }
+        ((uint32_t*)kbox)[32] = valid;
+    }
+    wg_sync();
+    const uint32_t valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t*)kbox)[32]);
+    uint32_t n_shadow = 0u, n_bounce = 0u, n_paths = 0u, parity = 0u;
+    PathState ps;
+#ifdef PTX_PHASE_TIMING
+    for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
+    ps.tick_last = clock64();
+#endif
+    for (;;) {
+        PoolPath* const cur = buf0 + (size_t)parity * M;
+        PoolPath* const nxt = buf0 + (size_t)(parity ^ 1u) * M;
+        uint32_t* const cur_keys = keys0 + (size_t)parity * M;
+        uint32_t* const nxt_keys = keys0 + (size_t)(parity ^ 1u) * M;
+        // ---- top-up: new paths for the places of those that ended
+        if (threadIdx.x == 0u) {
+            const uint32_t have = cv[0];
+            const uint32_t need = (cv[4] != 0u || P.n == 0u || have >= M) ? 0u : M - have;
+            cv[5] = need;
+            if (need > 0u) {
+                const uint32_t base = atomicAdd(P.job_counter, need);
+                cv[3] = base;
+                if (base + need >= P.total_jobs) cv[4] = 1u;  // the launch's last jobs are among these
+            }
+        }
+        wg_sync();
+        {
+            const uint32_t need = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[5]);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[3]);
+            for (uint32_t j = threadIdx.x; j < need; j += PTX_BLOCK) {
+                const uint32_t job = base + j;
+                PixelJob J;
+                if (job < P.total_jobs && job_pixel(P, job, J, true)) {
+                    ps.rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + J.k) * 16777259u);  // random.wgsl:12-14
+                    ps.ray = generate_ray(P.cam, ps.rng, (float)J.px, (float)J.py);
+                    ps.throughput = v3(1.0f, 1.0f, 1.0f);
+                    ps.radiance = v3(0.0f, 0.0f, 0.0f);
+                    ps.bounce = 0u;
+                    const uint32_t pos = atomicAdd(&cv[0], 1u);
+                    if (pos < M) {
+                        pool_store(cur + pos, ps, job, 0xFFFFFFFFu);
+                        cur_keys[pos] = regroup_key(kbox, valid, ps.ray);
+                    }
+                }
+            }
+        }
+        if (threadIdx.x < RG_BINS) hist[threadIdx.x] = 0u;
+        if (threadIdx.x == RG_BINS) { cv[1] = 0u; cv[2] = 0u; }
+        wg_sync();
+        uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[0]);
+        if (count > M) count = M;
+        if (count == 0u) break;  // the same for every wave of the workgroup
+        // ---- sort: the order the current buffer is traced in
+        for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[cur_keys[i] & (RG_BINS - 1u)], 1u);
+        wg_sync();
+        if (wave == 0u) {
+            const uint32_t a = hist[2u * lane], b = hist[2u * lane + 1u];
+            const uint32_t incl = wave_incl_scan(a + b);
+            offs[2u * lane] = incl - (a + b);
+            offs[2u * lane + 1u] = incl - b;
+        }
+        wg_sync();
+        for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) {
+            const uint32_t pos = atomicAdd(&offs[cur_keys[i] & (RG_BINS - 1u)], 1u);
+            if (pos < M) order[pos] = i;
+        }
+        wg_sync();
+        // ---- trace: one bounce of every path of the buffer, 64 at a time in sorted order
+        for (;;) {
+            uint32_t chunk = 0u;
+            if (lane == 0u) chunk = atomicAdd(&cv[2], 1u);
+            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+            if (chunk * 64u >= count) break;
+            const uint32_t i = chunk * 64u + lane;
+            const bool have = i < count;
+            uint32_t idx = have ? order[i] : 0u;
+            if (idx >= M) idx = 0u;
+            const float4* q = (const float4*)(cur + idx);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            ps.ray.o = v3(q0.x, q0.y, q0.z); ps.rng = __float_as_uint(q0.w);
+            ps.ray.d = v3(q1.x, q1.y, q1.z); ps.bounce = __float_as_uint(q1.w);
+            ps.throughput = v3(q2.x, q2.y, q2.z);
+            const uint32_t job = __float_as_uint(q2.w);
+            ps.radiance = v3(q3.x, q3.y, q3.z);
+            uint32_t primary = __float_as_uint(q3.w);
+            bool keep = false;
+            if (have) {
+                bool done = true;
+                if (ps.bounce < P.cam.max_bounces) {
+                    uint32_t fig;
+                    n_bounce += 1u;
+                    const bool first = ps.bounce == 0u;
+                    done = bounce_step<FRAC, false>(sc, P.cam, ps, st, park, fig, n_shadow);
+                    PT_TICK(3);
+                    if (first) primary = fig;
+                    if (!done && ps.bounce >= P.cam.max_bounces) done = true;
+                }
+                if (done) {
+                    PT_SITE(36);
+                    PixelJob J;
+                    job_pixel(P, job, J, true);
+                    float* slot = (float*)&P.staging[(size_t)J.k * P.frame_pixels + J.pix];
+                    slot[0] = dm::fmax_(ps.radiance.x, 0.0f); slot[1] = dm::fmax_(ps.radiance.y, 0.0f); slot[2] = dm::fmax_(ps.radiance.z, 0.0f);
+                    ((uint32_t*)slot)[3] = primary;
+                    n_paths += 1u;
+                } else {
+                    keep = true;
+                }
+            }
+            const unsigned long long going = __ballot(keep);
+            if (going != 0ull) {
+                uint32_t pos0 = 0u;
+                if (lane == (uint32_t)__ffsll((long long)going) - 1u) pos0 = atomicAdd(&cv[1], (uint32_t)__popcll(going));
+                pos0 = (uint32_t)__builtin_amdgcn_readlane((int)pos0, (int)((uint32_t)__ffsll((long long)going) - 1u));
+                if (keep) {
+                    const uint32_t pos = pos0 + (uint32_t)__popcll(going & ((1ull << lane) - 1ull));
+                    if (pos < M) {
+                        pool_store(nxt + pos, ps, job, primary);
+                        nxt_keys[pos] = regroup_key(kbox, valid, ps.ray);
+                    }
+                }
+            }
+        }
+        wg_sync();  // every chunk is done, every append made
+        if (threadIdx.x == 0u) cv[0] = cv[1];
+        parity ^= 1u;
+    }
+    const uint32_t sp = wave_sum(n_paths), sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
+    if (lane == 0u && P.stats) {
+        atomicAdd(&P.stats[0], (unsigned long long)sp);
+        atomicAdd(&P.stats[1], (unsigned long long)sb);
+        atomicAdd(&P.stats[2], (unsigned long long)ss);
+    }
+}
+
 // The wave-scheduled kernel body (sched_dev.h): same buffers and results as trace_body; the grid is sized to
 // the GPU, not to the frame, and lanes claim pixels as they go.
 static_assert(SC_PIXEL_FIELDS + SC_PARK_FIELDS == PT_PIXEL_FIELDS + PT_PARK_FIELDS, "both kernel families share one LDS budget");
@@ -544,6 +788,7 @@ extern "C" __global__ void __launch_bounds__(256) ptx_fold_kernel(const TracePar
 // Without them the kernel fits 128 VGPRs (4 waves per SIMD); with them 3 waves.
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false, PTX_CLAIM_LDS>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds_sorted(const TraceParams P) { sorted_body<false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true, PTX_CLAIM_LDS>(P); }
 #ifndef PTX_SCHED_WAVES
@@ -758,6 +1003,8 @@ struct ptx_ctx {
         uint32_t split_chunk = 0; // 0 = as many samples per chunk as the staging bound allows
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
+        int sorted_pool = -1;     // -1 per scene and launch, 0 / 1: lockstep LDS kernel over sorted path pools (sample jobs, long launches)
+        uint32_t pool_paths = 0;  // 0 = 4096, else paths per workgroup pool (a power of two from 256 to 16384)
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
         int64_t split_upto = -1;  // split_small: -1 per scene, else launches of up to this many samples run sample jobs (fractal scenes on the scheduled kernels always do)
         uint32_t flights = 0;     // launches of sample-granular jobs in flight at once; 0 = as many as the staging bound allows (at most PTX_FLIGHTS)
@@ -789,6 +1036,12 @@ struct ptx_ctx {
     WaveState* wave_state = nullptr;  // claim record of every wave of the largest grid so far (the kernels initialise their own)
     size_t wave_state_n = 0;
     unsigned char* static_scratch = nullptr;  // this device's copy of ptx_static_scratch (its address, not the host-side symbol)
+    // sorted path pools (ptx_trace_kernel_lds_sorted): for pool_wgs workgroups, pool_m paths each
+    PoolPath* pool = nullptr;
+    uint32_t* pool_keys = nullptr;
+    uint32_t* pool_order = nullptr;
+    size_t pool_wgs = 0;
+    uint32_t pool_m = 0;
     // multi-GPU exchange (collective.h)
     ncclComm_t comm = nullptr;
     bool comm_owned = false;      // created by ptx_comm_init (destroyed with the context) or handed in by ptx_comm_adopt
@@ -1048,6 +1301,9 @@ void ptx_destroy(ptx_ctx* c) {
         if (f.spill) (void)hipFree(f.spill);
     }
     if (c->flight_counters) (void)hipFree(c->flight_counters);
+    if (c->pool) (void)hipFree(c->pool);
+    if (c->pool_keys) (void)hipFree(c->pool_keys);
+    if (c->pool_order) (void)hipFree(c->pool_order);
     if (c->barrier) (void)hipEventDestroy(c->barrier);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1074,6 +1330,8 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "share_march") { if ((ok = in(0, 64))) o.shares[2] = (uint32_t)value; }
     else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
     else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
+    else if (k == "sorted_pool") { if ((ok = in(-1, 1))) o.sorted_pool = (int)value; }
+    else if (k == "pool_paths") { if ((ok = value == 0 || (value >= 256 && value <= 16384 && (value & (value - 1)) == 0))) o.pool_paths = (uint32_t)value; }
     else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
     else if (k == "flights") { if ((ok = in(0, PTX_FLIGHTS))) o.flights = (uint32_t)value; }
     else if (k == "verbose") { o.verbose = value != 0; }
@@ -1508,6 +1766,25 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             P.sc.lds_stack_entries = c->sc.stack_entries < more ? c->sc.stack_entries : more;
         }
     }
+    // Long launches of sample jobs on the lockstep LDS kernels trace from sorted path pools (sorted_body); short ones, whose
+    // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
+    const bool sorted = split && !c->sched && !frac && c->sc.lds_scene_bytes > 0u && n > 4u && c->opt.sorted_pool != 0;
+    if (sorted) {
+        const uint32_t m = c->opt.pool_paths ? c->opt.pool_paths : 4096u;
+        if ((size_t)grid > c->pool_wgs || m != c->pool_m) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->pool) (void)hipFree(c->pool);
+            if (c->pool_keys) (void)hipFree(c->pool_keys);
+            if (c->pool_order) (void)hipFree(c->pool_order);
+            c->pool = nullptr; c->pool_keys = nullptr; c->pool_order = nullptr; c->pool_wgs = 0; c->pool_m = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->pool, (size_t)grid * 2u * m * sizeof(PoolPath)));
+            HIP_TRY(c, hipMalloc((void**)&c->pool_keys, (size_t)grid * 2u * m * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void**)&c->pool_order, (size_t)grid * m * sizeof(uint32_t)));
+            c->pool_wgs = grid; c->pool_m = m;
+        }
+        P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;
+        kernel = ptx_trace_kernel_lds_sorted;  // same LDS, four waves per SIMD
+    }
     uint32_t chunk = n;
     size_t frame_pixels = 0;
     uint32_t depth = 1;
@@ -1529,6 +1806,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         // which also keeps every kernel's duration a quantity of its own.
         if (!frac && n > 4u) depth = 1u;
         if (c->opt.flights >= 1u) depth =c->opt.flights < in_flight || c->opt.flights <= 2u ? c->opt.flights : (in_flight < 2 ? 2u : (uint32_t)in_flight);
+        if (sorted) depth = 1u;  // one set of pools per context
         if (!c->flight_counters) HIP_TRY(c, hipMalloc((void**)&c->flight_counters, PTX_FLIGHTS * 256));
         if (!c->barrier) HIP_TRY(c, hipEventCreateWithFlags(&c->barrier, hipEventDisableTiming));
     } else {
@@ -1588,7 +1866,8 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         P.staging = f.staging;
         P.wave_state = f.wave_state;
         P.job_counter = c->flight_counters + slot * 64u;
-        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, f.stream));
+        // the lane-owned kernels start with jobs 0 .. grid * 256 - 1 in their lanes; the pools reserve every job they trace
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, sorted ? 0 : (int)(grid * 256u), 1, f.stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, f.stream, P);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(f.traced, f.stream));

@@ -51,7 +51,21 @@ struct TraceParams {
     // kernel folds the samples of each pixel into its running mean in sample order afterwards.
     uint32_t split_n, frame_pixels;
     float4* staging;
+    // Sorted path pools (ptx_trace_kernel_lds_sorted): per workgroup two buffers of pool_m path records, their keys, and the
+    // order the current buffer is traced in.
+    struct PoolPath* pool;
+    uint32_t* pool_keys;
+    uint32_t* pool_order;
+    uint32_t pool_m;
 };
+// A path between two bounces: 64 bytes = four 16-byte accesses.
+struct alignas(16) PoolPath {
+    float o[3]; uint32_t rng;
+    float d[3]; uint32_t bounce;
+    float thr[3]; uint32_t job;
+    float rad[3]; uint32_t primary;
+};
+static_assert(sizeof(PoolPath) == 64, "PoolPath");
 
 // LS_LEAF (one-visit-per-step mode only): the lane stands at a leaf primitive it has yet to test.
 enum : uint32_t { LS_IDLE = 0, LS_WALK = 1, LS_POST = 2, LS_TORUS = 3, LS_MEBIUS = 4, LS_MANDEL = 5, LS_JULIA = 6, LS_LEAF = 7, LS_COUNT = 8 };
