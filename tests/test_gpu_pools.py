@@ -1,0 +1,105 @@
+"""GPU tier: the lockstep kernel over sorted path pools (long launches of sample jobs on scenes staged in LDS) against the
+CPU oracle and against the lane-owned kernel: accumulation, M2, primary ids, rgba8 and counters bit for bit -- with pools
+smaller than a workgroup's first fill, pools larger than the whole launch, frames that are no multiple of the 16x16 blocks,
+tiles and partitions, bounce limits 0 and 1, continued accumulation."""
+import numpy as np
+import pytest
+
+from oracle import host_prep as hp, oracle as orc
+from pathtracer_amd import host
+from pathtracer_amd.device import PathTracer
+from util import fixture, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    t = PathTracer(0)
+    yield t
+    t.reset_options()
+    t.close()
+
+
+def _render(pt, sc, cam, w, h, plan, **opts):
+    pt.reset_options()
+    pt.set_options(**opts)
+    sc.upload_to(pt)
+    pt.enable_moments(True)
+    pt.resize(w, h)
+    for first_frame, first_sample, n in plan:
+        pt.trace_n(cam, first_frame, first_sample, n)
+    st = pt.stats()
+    out = (pt.read_accum(), pt.read_moments(), pt.read_primary_ids(), pt.read_output(), (st["paths"], st["bounces"], st["shadow_rays"]), pt.kernel_name())
+    pt.enable_moments(False)
+    pt.reset_options()
+    return out
+
+
+def _same(a, b):
+    return same_bits(a[0], b[0]) == 0 and same_bits(a[1], b[1]) == 0 and (a[2] == b[2]).all() and (a[3] == b[3]).all() and a[4] == b[4]
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "planet", "rings", "torus", "pyramid", "hyperboloid", "earth", "aelita"])
+def test_pools_match_the_oracle(pt, name):
+    sc = host.Scene.from_fixture(fixture(name)).build()
+    sb = hp.prepare_fixture(fixture(name))
+    w, h, n = 131, 77, 9
+    cam = sc.camera(w, h)
+    ref = orc.render(orc.OracleScene(sb), cam, n, want_m2=True, counters=True)
+    c = ref["counters"]
+    want = (ref["accum"], ref["m2"], ref["primary_id"], ref["rgba8"], (c["paths"], c["bounces"], c["shadow_rays"]))
+    for pool in (0, 256, 16384):  # the default, one that is refilled many times, one that never fills
+        got = _render(pt, sc, cam, w, h, [(0, 1, n)], sorted_pool=1, pool_paths=pool)
+        assert _same(got, want), (name, pool)
+
+
+def test_pools_equal_lane_owned_paths_with_tiles_partitions_and_continuation(pt):
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h = 203, 117
+    cam = sc.camera(w, h)
+    plan = [(0, 1, 6), (6, 7, 11), (17, 18, 5)]
+    a = _render(pt, sc, cam, w, h, plan, sorted_pool=0)
+    b = _render(pt, sc, cam, w, h, plan, sorted_pool=1)
+    assert _same(a, b)
+    # a tile of the frame, and the four interleaved partitions of it: every rank's blocks from pools, summed
+    pt.reset_options()
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.set_tile(16, 32, 150, 70)
+    pt.set_option("sorted_pool", 0)
+    pt.trace_n(cam, 0, 1, 8)
+    whole = pt.read_accum()
+    pt.set_option("sorted_pool", 1)
+    total = np.zeros_like(whole)
+    for r in range(4):
+        pt.clear()
+        pt.set_partition(r, 4)
+        pt.trace_n(cam, 0, 1, 8)
+        total += pt.read_accum()
+    pt.set_partition(0, 1)
+    pt.set_tile(0, 0, w, h)
+    pt.reset_options()
+    assert same_bits(total, whole) == 0
+
+
+@pytest.mark.parametrize("max_bounces", [0, 1, 3])
+def test_pools_with_short_bounce_limits(pt, max_bounces):
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h = 97, 61
+    cam = sc.camera(w, h)
+    cam[0]["max_bounces"] = max_bounces
+    a = _render(pt, sc, cam, w, h, [(0, 1, 7)], sorted_pool=0)
+    b = _render(pt, sc, cam, w, h, [(0, 1, 7)], sorted_pool=1, pool_paths=512)
+    assert _same(a, b) and a[4][0] == w * h * 7
+    assert a[4][1] == (0 if max_bounces == 0 else a[4][1])
+
+
+def test_launch_lengths_pick_the_kernel_form(pt):
+    """Launches of up to four samples keep lane-owned paths (they overlap with their neighbours); longer ones trace from pools."""
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h = 64, 48
+    cam = sc.camera(w, h)
+    a = _render(pt, sc, cam, w, h, [(k, k + 1, 1) for k in range(12)])
+    b = _render(pt, sc, cam, w, h, [(0, 1, 12)])
+    assert _same(a, b)

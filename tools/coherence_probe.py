@@ -71,7 +71,11 @@ for i in range(ts.shape[1]):
     key |= (ts[:, i] < np.inf).astype(np.int64) << (3 + i)
 rank = np.argsort(np.argsort(ts, axis=1), axis=1)  # the order the boxes would be entered in
 key = key * 64 + rank[:, 0] * 16 + rank[:, 1] * 4 + (rank[:, 2] if ts.shape[1] > 2 else 0)
-orders = [rng.permutation(n), np.argsort(key, kind="stable"), np.lexsort((fig, key)), np.argsort(fig, kind="stable")]
+octant = (d_all[:, 0] > 0).astype(np.int64) | ((d_all[:, 1] > 0).astype(np.int64) << 1) | ((d_all[:, 2] > 0).astype(np.int64) << 2)
+mask_only = key // 64
+orders = [rng.permutation(n), np.argsort(key, kind="stable"), np.lexsort((fig, key)), np.argsort(fig, kind="stable"),
+          np.argsort(mask_only, kind="stable"), np.lexsort((octant, key)), np.lexsort((octant, fig, key)), np.lexsort((key, fig))]
+print("orders: 0 random, 1 key, 2 key+figure, 3 figure, 4 hit mask only, 5 key+octant, 6 key+figure+octant, 7 figure+key", flush=True)
 print(f"{name}: {n} secondary rays, {len(np.unique(key))} keys, {len(leaves)} key boxes; figures started from: {np.bincount(fig.astype(np.int64))}", flush=True)
 rays = np.concatenate([o_all, d_all], axis=1)
 ref = None
