@@ -995,6 +995,7 @@ struct ptx_ctx {
     bool split = true;            // sample-granular jobs + fold where they pay (launch_trace)
     uint32_t split_upto = 0x7FFFFFFFu;  // launches of up to this many samples use them (configure(): per scene)
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
+    const char* last_kernel = nullptr;  // the trace kernel of the latest launch since the scene was uploaded
     // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
     struct Options {
         int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
@@ -1357,6 +1358,14 @@ static bool pick_sched(const DScene& sc, uint32_t type_mask, int forced) {
 }
 
 typedef void (*TraceKernel)(const TraceParams);
+static const char* trace_kernel_label(TraceKernel k) {
+#define PTX_NAME(f) if (k == f) return #f;
+    PTX_NAME(ptx_trace_kernel) PTX_NAME(ptx_trace_kernel_lds) PTX_NAME(ptx_trace_kernel_lds_sorted) PTX_NAME(ptx_trace_kernel_frac)
+    PTX_NAME(ptx_trace_kernel_lds_frac) PTX_NAME(ptx_sched_kernel) PTX_NAME(ptx_sched_kernel_lds) PTX_NAME(ptx_sched_kernel_samples)
+    PTX_NAME(ptx_sched_kernel_lds_samples) PTX_NAME(ptx_sched_kernel_frac) PTX_NAME(ptx_sched_kernel_lds_frac)
+#undef PTX_NAME
+    return "";
+}
 static TraceKernel trace_kernel_of(const ptx_ctx* c) {
     const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
     return c->sched ? (lds ? (frac ? ptx_sched_kernel_lds_frac : ptx_sched_kernel_lds) : (frac ? ptx_sched_kernel_frac : ptx_sched_kernel))
@@ -1608,6 +1617,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     }
     c->sc = sc;
     c->have_scene = true;
+    c->last_kernel = nullptr;
     c->type_mask = type_mask;
     if ((rc = configure(c))) { free_scene(c); return rc; }
     return PTX_OK;
@@ -1785,6 +1795,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;
         kernel = ptx_trace_kernel_lds_sorted;  // same LDS, four waves per SIMD
     }
+    c->last_kernel = trace_kernel_label(kernel);
     uint32_t chunk = n;
     size_t frame_pixels = 0;
     uint32_t depth = 1;
@@ -2317,6 +2328,7 @@ int ptx_post_process(ptx_ctx* c, const ptx_post_params* pp) {
 
 const char* ptx_trace_kernel_name(const ptx_ctx* c) {
     if (!c || !c->have_scene) return "";
+    if (c->last_kernel) return c->last_kernel;  // what the latest launch ran (the form depends on the launch's length)
     const bool frac = c->sc.has_fractals != 0u, lds = c->sc.lds_scene_bytes > 0u;
     const bool samples = c->split && c->split_upto > 2u;  // launches of every size run sample jobs (launch_trace)
     if (c->sched && !frac) return lds ? (samples ? "ptx_sched_kernel_lds_samples" : "ptx_sched_kernel_lds") : (samples ? "ptx_sched_kernel_samples" : "ptx_sched_kernel");
