@@ -421,15 +421,23 @@ PT_DEV void sorted_body(const TraceParams& P) {
             if (pos < M) order[pos] = i;
         }
         wg_sync();
-        // ---- trace: one bounce of every path of the buffer, 64 at a time in sorted order
+        // ---- trace: one bounce of every path of the buffer, 64 at a time in sorted order.  A wave claims its next chunk and
+        // reads that chunk's places in the order before it traces the current one: only the records' load waits on memory.
+        auto claim_chunk = [&](uint32_t& chunk, uint32_t& idx) {
+            uint32_t c2 = 0u;
+            if (lane == 0u) c2 = atomicAdd(&cv[2], 1u);
+            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)c2);
+            const uint32_t i2 = chunk * 64u + lane;
+            idx = (chunk * 64u < count && i2 < count) ? order[i2] : 0u;
+        };
+        uint32_t chunk_n, idx_n;
+        claim_chunk(chunk_n, idx_n);
         for (;;) {
-            uint32_t chunk = 0u;
-            if (lane == 0u) chunk = atomicAdd(&cv[2], 1u);
-            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+            const uint32_t chunk = chunk_n;
+            uint32_t idx = idx_n;
             if (chunk * 64u >= count) break;
             const uint32_t i = chunk * 64u + lane;
             const bool have = i < count;
-            uint32_t idx = have ? order[i] : 0u;
             if (idx >= M) idx = 0u;
             const float4* q = (const float4*)(cur + idx);
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -439,6 +447,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
             const uint32_t job = __float_as_uint(q2.w);
             ps.radiance = v3(q3.x, q3.y, q3.z);
             uint32_t primary = __float_as_uint(q3.w);
+            claim_chunk(chunk_n, idx_n);
             bool keep = false;
             if (have) {
                 bool done = true;
