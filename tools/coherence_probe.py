@@ -85,3 +85,38 @@ for i, order in enumerate(orders):
     back[order] = hid
     ref = back if ref is None else ref
     print(f"order {i}: dispatched; same hits as order 0: {bool((back == ref).all())}", flush=True)
+
+# ---- the occlusion query: rays from the same surface points to points on the scene's lights (next-event estimation), closest-hit
+# order of the rays that made the points against orders of their own
+b = sc.buffers()
+lights = b["lights"]
+if len(lights):
+    figs = b["figs"]
+    li = rng.integers(0, len(lights), size=n)
+    lp = figs["position"][lights[li]].astype(f32)
+    lr = figs["radius"][lights[li]].astype(f32)
+    u = rng.normal(size=(n, 3)).astype(f32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True).astype(f32)
+    target = lp + u * lr[:, None]
+    to = target - o_all
+    dist = np.linalg.norm(to, axis=1).astype(f32)
+    sd = (to / dist[:, None]).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = (f32(1) / sd).astype(f32)
+        ts2 = []
+        for k in leaves:
+            t1 = (nodes[k]["aabb_min"] - o_all) * inv
+            t2 = (nodes[k]["aabb_max"] - o_all) * inv
+            tn, tf = np.minimum(t1, t2).max(axis=1), np.maximum(t1, t2).min(axis=1)
+            ts2.append(np.where((tn > tf) | (tf < 0) | (np.maximum(tn, 0) >= dist), f32(np.inf), np.maximum(tn, f32(0))))
+    ts2 = np.stack(ts2, axis=1)
+    skey = np.zeros(n, dtype=np.int64)
+    for i in range(ts2.shape[1]):
+        skey |= (ts2[:, i] < np.inf).astype(np.int64) << i
+    sorders = [orders[0], orders[1], np.argsort(skey, kind="stable"), np.lexsort((li, skey)), np.lexsort((skey, li)), np.argsort(li, kind="stable")]
+    print("occlusion orders: 0 random, 1 the closest-hit key of the ray that starts at the same point, 2 occlusion key (boxes entered before the light), "
+          "3 occlusion key + light, 4 light + occlusion key, 5 light", flush=True)
+    srays = np.concatenate([o_all, sd], axis=1)
+    for i, order in enumerate(sorders):
+        pt.kat_trace(cam, srays[order], dist[order])
+        print(f"occlusion order {i}: dispatched", flush=True)
