@@ -299,18 +299,18 @@ PT_DEV void pool_store(PoolPath* dst, const PathState& ps, uint32_t job, uint32_
     q[2] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, __uint_as_float(job));
     q[3] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, __uint_as_float(primary));
 }
-template <bool FRAC>
+template <bool LDS_SCENE, bool FRAC>
 PT_DEV void sorted_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr uint32_t kSlots = PT_PIXEL_FIELDS + PT_PARK_FIELDS;
     WalkStack st;
     st.lds = lds_stack + (size_t)wave * P.sc.lds_stack_entries * 64u + lane;
-    st.glb = nullptr;
+    st.glb = LDS_SCENE ? nullptr : walk_stack_glb(P.stack_spill, blockIdx.x * PTX_WAVES_PER_BLOCK + wave, lane);
     st.nl = P.sc.lds_stack_entries;
     float* fields = (float*)(lds_stack + (size_t)PTX_WAVES_PER_BLOCK * P.sc.lds_stack_entries * 64u);
     DScene sc = P.sc;
-    {
+    if (LDS_SCENE) {
         char* base = (char*)(fields + (size_t)PTX_WAVES_PER_BLOCK * kSlots * 64u);
         uint32_t off = 0;
         auto stage = [&](const void* src, uint32_t bytes) -> void* {
@@ -455,7 +455,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
                     uint32_t fig;
                     n_bounce += 1u;
                     const bool first = ps.bounce == 0u;
-                    done = bounce_step<FRAC, false>(sc, P.cam, ps, st, park, fig, n_shadow);
+                    done = bounce_step<FRAC, !LDS_SCENE>(sc, P.cam, ps, st, park, fig, n_shadow);
                     PT_TICK(3);
                     if (first) primary = fig;
                     if (!done && ps.bounce >= P.cam.max_bounces) done = true;
@@ -797,7 +797,8 @@ extern "C" __global__ void __launch_bounds__(256) ptx_fold_kernel(const TracePar
 // Without them the kernel fits 128 VGPRs (4 waves per SIMD); with them 3 waves.
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false, PTX_CLAIM_LDS>(P); }
-extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds_sorted(const TraceParams P) { sorted_body<false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds_sorted(const TraceParams P) { sorted_body<true, false>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_sorted(const TraceParams P) { sorted_body<false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_lds_frac(const TraceParams P) { trace_body<true, true, PTX_CLAIM_LDS>(P); }
 #ifndef PTX_SCHED_WAVES
@@ -1369,7 +1370,7 @@ static bool pick_sched(const DScene& sc, uint32_t type_mask, int forced) {
 typedef void (*TraceKernel)(const TraceParams);
 static const char* trace_kernel_label(TraceKernel k) {
 #define PTX_NAME(f) if (k == f) return #f;
-    PTX_NAME(ptx_trace_kernel) PTX_NAME(ptx_trace_kernel_lds) PTX_NAME(ptx_trace_kernel_lds_sorted) PTX_NAME(ptx_trace_kernel_frac)
+    PTX_NAME(ptx_trace_kernel) PTX_NAME(ptx_trace_kernel_lds) PTX_NAME(ptx_trace_kernel_lds_sorted) PTX_NAME(ptx_trace_kernel_sorted) PTX_NAME(ptx_trace_kernel_frac)
     PTX_NAME(ptx_trace_kernel_lds_frac) PTX_NAME(ptx_sched_kernel) PTX_NAME(ptx_sched_kernel_lds) PTX_NAME(ptx_sched_kernel_samples)
     PTX_NAME(ptx_sched_kernel_lds_samples) PTX_NAME(ptx_sched_kernel_frac) PTX_NAME(ptx_sched_kernel_lds_frac)
 #undef PTX_NAME
@@ -1717,7 +1718,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
-    const bool claim = c->sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u);
+    const bool claim = c->sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (c->opt.sorted_pool == 1 && !frac && n > 4u);  // the pools' grid is the resident workgroups too
     uint32_t grid = P.n_blocks;
     if (claim) {
         int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
@@ -1787,7 +1788,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     }
     // Long launches of sample jobs on the lockstep LDS kernels trace from sorted path pools (sorted_body); short ones, whose
     // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !c->sched && !frac && c->sc.lds_scene_bytes > 0u && n > 4u && c->opt.sorted_pool != 0;
+    const bool sorted = split && !c->sched && !frac && n > 4u && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : c->opt.sorted_pool == 1);
     if (sorted) {
         const uint32_t m = c->opt.pool_paths ? c->opt.pool_paths : 4096u;
         if ((size_t)grid > c->pool_wgs || m != c->pool_m) {
@@ -1802,7 +1803,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             c->pool_wgs = grid; c->pool_m = m;
         }
         P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;
-        kernel = ptx_trace_kernel_lds_sorted;  // same LDS, four waves per SIMD
+        kernel = c->sc.lds_scene_bytes > 0u ? ptx_trace_kernel_lds_sorted : ptx_trace_kernel_sorted;  // same LDS, four waves per SIMD
     }
     c->last_kernel = trace_kernel_label(kernel);
     uint32_t chunk = n;

@@ -54,6 +54,22 @@ def test_pools_match_the_oracle(pt, name):
         assert _same(got, want), (name, pool)
 
 
+@pytest.mark.parametrize("name", ["teapot", "unit_logo", "all"])
+def test_pools_over_scenes_read_from_global_memory(pt, name):
+    """Opt-in (kernel_family 0 + sorted_pool 1): the lockstep kernel over sorted pools with the scene records in global memory
+    and the traversal stack partly there -- meshes, which the wave-scheduled kernels run by default."""
+    sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
+    sb = hp.prepare_fixture(fixture(name))
+    w, h, n = 90, 52, 6
+    cam = sc.camera(w, h)
+    ref = orc.render(orc.OracleScene(sb), cam, n, want_m2=True, counters=True)
+    c = ref["counters"]
+    want = (ref["accum"], ref["m2"], ref["primary_id"], ref["rgba8"], (c["paths"], c["bounces"], c["shadow_rays"]))
+    got = _render(pt, sc, cam, w, h, [(0, 1, n)], kernel_family=0, sorted_pool=1, split_small=64, pool_paths=1024)
+    assert _same(got, want)
+    assert got[5] == ("ptx_trace_kernel_sorted" if name != "all" else got[5])  # all.yaml fits LDS: the LDS form
+
+
 def test_pools_equal_lane_owned_paths_with_tiles_partitions_and_continuation(pt):
     sc = host.Scene.from_fixture(fixture("cornell_box")).build()
     w, h = 203, 117

@@ -14,7 +14,8 @@ CASES = [("cornell_box", 1920, 1080, (32, 128)), ("teapot", 3840, 2160, (8,)), (
          ("all_mesh", 1920, 1080, (8,))]  # all_mesh: all.yaml + the 10 M-triangle height field of bench.py --workload all_mesh
 print("library:", _lib.LIB_PATH)
 if len(sys.argv) > 1:
-    CASES = [c for c in CASES if c[0] in sys.argv[1:]]
+    known = {c[0] for c in CASES}
+    CASES = [c for c in CASES if c[0] in sys.argv[1:]] + [(a, 1920, 1080, (16,)) for a in sys.argv[1:] if a not in known]  # any other fixture
 if os.environ.get("PROBE_N"):  # samples per launch, e.g. PROBE_N=2,8
     CASES = [(c[0], c[1], c[2], tuple(int(x) for x in os.environ["PROBE_N"].split(","))) for c in CASES]
 pt = PathTracer(0)
@@ -29,6 +30,8 @@ for name, w, h, ns in CASES:
         sc.build(decode_textures=False, tracer=pt)
     else:
         sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{name}.npz")).build(decode_textures=False)
+    if os.environ.get("PROBE_SIZE"):  # WxH for every case
+        w, h = (int(x) for x in os.environ["PROBE_SIZE"].split("x"))
     cam = sc.camera(w, h)
     sc.upload_to(pt)
     pt.resize(w, h)
