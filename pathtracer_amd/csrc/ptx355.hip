@@ -1714,11 +1714,16 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     P.stats = c->stats;
     const bool frac = c->sc.has_fractals != 0u;
     const size_t lds_all = trace_lds_bytes(c);
-    TraceKernel kernel = trace_kernel_of(c);
+    // Small scenes with a Moebius strip (staged in LDS, wave-scheduled by the per-scene rule): launches of more than four samples
+    // run the lockstep kernel over sorted path pools instead (all.yaml 25.1 -> 21.8 ms per 16 samples at 1080p, mebius.yaml
+    // 17.3 -> 14.6; lane-owned lockstep 27.5 / 15.8), shorter ones stay wave-scheduled.  Same LDS bytes, same occupancy.
+    const bool sched = c->sched && !(c->opt.family < 0 && c->opt.sorted_pool != 0 && c->sc.lds_scene_bytes > 0u && !frac && n > 4u && !fixed &&
+                                     c->split && !c->dbg && n <= c->split_upto);
+    TraceKernel kernel = sched == c->sched ? trace_kernel_of(c) : ptx_trace_kernel_lds;
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
-    const bool claim = c->sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (c->opt.sorted_pool == 1 && !frac && n > 4u);  // the pools' grid is the resident workgroups too
+    const bool claim = sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (c->opt.sorted_pool == 1 && !frac && n > 4u);  // the pools' grid is the resident workgroups too
     uint32_t grid = P.n_blocks;
     if (claim) {
         int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
@@ -1756,11 +1761,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         // Lockstep kernels: short launches are bound by the rate of the claims (one device atomic per finished pixel and wave),
         // long ones lose 4 % when a wave's lanes sit on neighbouring pixels (Cornell box, 1080p: 1.3 ms against 2.0 at one sample
         // per launch, 15.6 against 17.1 at 16, 30.1 against 29.1 at 32).
-        if (!c->opt.claim_tile && !c->sched && !frac && n <= 16u) P.claim_tile = 64u;
+        if (!c->opt.claim_tile && !sched && !frac && n <= 16u) P.claim_tile = 64u;
         // Scheduled kernels on frames of 4 M pixels and more, one or two samples per launch: even one claim per 64 pixels is
         // 130 k atomics on one address (teapot 4K, one sample per launch: 2.1 ms, 1.7 ms with 128 pixels per claim; longer
         // launches and smaller frames are 3-6 % faster with 64).
-        if (!c->opt.claim_tile && c->sched && !frac && n <= 2u && P.n_blocks >= 16384u) P.claim_tile = 128u;
+        if (!c->opt.claim_tile && sched && !frac && n <= 2u && P.n_blocks >= 16384u) P.claim_tile = 128u;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
         if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
@@ -1778,7 +1783,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // meshes without marched figures.  Staging costs 16 bytes per sample, written once and read once: 4.2 GB per 128-sample
     // launch of a 1080p frame, two such buffers in flight.
     const bool split = !fixed && claim && c->split && !c->dbg && n <= c->split_upto;
-    if (split && c->sched && !frac) {
+    if (split && sched && !frac) {
         kernel = c->sc.lds_scene_bytes > 0u ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
         // the slots of the running mean, which sample jobs do not keep, hold two more stack entries (same LDS bytes: sched_body)
         if (c->sc.lds_scene_bytes == 0u && c->sc.stack_entries > PT_LDS_STACK) {
@@ -1788,7 +1793,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     }
     // Long launches of sample jobs on the lockstep LDS kernels trace from sorted path pools (sorted_body); short ones, whose
     // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !c->sched && !frac && n > 4u && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : c->opt.sorted_pool == 1);
+    const bool sorted = split && !sched && !frac && n > 4u && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : c->opt.sorted_pool == 1);
     if (sorted) {
         const uint32_t m = c->opt.pool_paths ? c->opt.pool_paths : 4096u;
         if ((size_t)grid > c->pool_wgs || m != c->pool_m) {
