@@ -1,15 +1,9 @@
 #!/bin/bash
-# One sample per dispatch: lane-owned overlapping launches against pools in turn (experiment).
+# GPU tests after a kernel change, then the default bench line twice.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for o in "" "--opt sorted_pool=2" "--opt flights=1"; do
-  echo "== cornell spp1 $o"
-  timeout -k 10 300 python3 bench.py --workload cornell --spp-per-step 1 --steps 64 --warmup 4 --no-cpu-baseline $o 2>/dev/null | python3 -c "
+timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/gputest_check.log 2>&1 || { echo "gpu tests failed"; tail -30 gpurun_out/gputest_check.log; exit 1; }
+tail -1 gpurun_out/gputest_check.log
+for i in 1 2; do timeout -k 10 300 python3 bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], 'Mpaths/s', d['ms_per_step'], 'ms/step', d['roofline']['kernel'])" || exit 1
-done
-for n in 2 4; do for o in "" "--opt sorted_pool=2"; do
-  echo "== cornell spp$n $o"
-  timeout -k 10 300 python3 bench.py --workload cornell --spp-per-step $n --steps 32 --warmup 4 --no-cpu-baseline $o 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], 'Mpaths/s', d['ms_per_step'], 'ms/step', d['roofline']['kernel'])" || exit 1
-done; done
+d=json.loads(sys.stdin.read()); print(d['value'], 'Mpaths/s', d['ms_per_step'], 'ms/step', d['gpath_bounce_per_s'], d['roofline']['kernel'])" || exit 1; done
+SORTED_N=16,32,64 timeout -k 10 200 python3 tools/sorted_probe.py 2>/dev/null | grep "sorted_pool=1" | tail -3
