@@ -336,8 +336,8 @@ PT_DEV void sorted_body(const TraceParams& P) {
     float* park = px_f + PT_PIXEL_FIELDS * 64u;
     const uint32_t M = P.pool_m;
     PoolPath* const buf0 = P.pool + (size_t)blockIdx.x * 2u * M;
-    uint32_t* const keys0 = P.pool_keys + (size_t)blockIdx.x * 2u * M;
-    uint32_t* const order = P.pool_order + (size_t)blockIdx.x * M;
+    uint8_t* const keys0 = P.pool_keys + (size_t)blockIdx.x * 2u * M;
+    uint16_t* const order = P.pool_order + (size_t)blockIdx.x * M;  // pool_m <= 16384
     if (threadIdx.x < 8u) cv[threadIdx.x] = 0u;
     if (threadIdx.x == 0u) {
         // the key boxes: the children of the root's children (a child that is a leaf stands for itself)
@@ -366,8 +366,8 @@ PT_DEV void sorted_body(const TraceParams& P) {
     for (;;) {
         PoolPath* const cur = buf0 + (size_t)parity * M;
         PoolPath* const nxt = buf0 + (size_t)(parity ^ 1u) * M;
-        uint32_t* const cur_keys = keys0 + (size_t)parity * M;
-        uint32_t* const nxt_keys = keys0 + (size_t)(parity ^ 1u) * M;
+        uint8_t* const cur_keys = keys0 + (size_t)parity * M;
+        uint8_t* const nxt_keys = keys0 + (size_t)(parity ^ 1u) * M;
         // ---- top-up: new paths for the places of those that ended
         if (threadIdx.x == 0u) {
             const uint32_t have = cv[0];
@@ -395,7 +395,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
                     const uint32_t pos = atomicAdd(&cv[0], 1u);
                     if (pos < M) {
                         pool_store(cur + pos, ps, job, 0xFFFFFFFFu);
-                        cur_keys[pos] = regroup_key(kbox, valid, ps.ray);
+                        cur_keys[pos] = (uint8_t)regroup_key(kbox, valid, ps.ray);
                     }
                 }
             }
@@ -407,7 +407,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
         if (count > M) count = M;
         if (count == 0u) break;  // the same for every wave of the workgroup
         // ---- sort: the order the current buffer is traced in
-        for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[cur_keys[i] & (RG_BINS - 1u)], 1u);
+        for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
         wg_sync();
         if (wave == 0u) {
             const uint32_t a = hist[2u * lane], b = hist[2u * lane + 1u];
@@ -417,8 +417,8 @@ PT_DEV void sorted_body(const TraceParams& P) {
         }
         wg_sync();
         for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) {
-            const uint32_t pos = atomicAdd(&offs[cur_keys[i] & (RG_BINS - 1u)], 1u);
-            if (pos < M) order[pos] = i;
+            const uint32_t pos = atomicAdd(&offs[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
+            if (pos < M) order[pos] = (uint16_t)i;
         }
         wg_sync();
         // ---- trace: one bounce of every path of the buffer, 64 at a time in sorted order.  A wave claims its next chunk and
@@ -428,7 +428,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
             if (lane == 0u) c2 = atomicAdd(&cv[2], 1u);
             chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)c2);
             const uint32_t i2 = chunk * 64u + lane;
-            idx = (chunk * 64u < count && i2 < count) ? order[i2] : 0u;
+            idx = (chunk * 64u < count && i2 < count) ? (uint32_t)order[i2] : 0u;
         };
         uint32_t chunk_n, idx_n;
         claim_chunk(chunk_n, idx_n);
@@ -481,7 +481,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
                     const uint32_t pos = pos0 + (uint32_t)__popcll(going & ((1ull << lane) - 1ull));
                     if (pos < M) {
                         pool_store(nxt + pos, ps, job, primary);
-                        nxt_keys[pos] = regroup_key(kbox, valid, ps.ray);
+                        nxt_keys[pos] = (uint8_t)regroup_key(kbox, valid, ps.ray);
                     }
                 }
             }
@@ -1049,8 +1049,8 @@ struct ptx_ctx {
     unsigned char* static_scratch = nullptr;  // this device's copy of ptx_static_scratch (its address, not the host-side symbol)
     // sorted path pools (ptx_trace_kernel_lds_sorted): for pool_wgs workgroups, pool_m paths each
     PoolPath* pool = nullptr;
-    uint32_t* pool_keys = nullptr;
-    uint32_t* pool_order = nullptr;
+    uint8_t* pool_keys = nullptr;
+    uint16_t* pool_order = nullptr;
     size_t pool_wgs = 0;
     uint32_t pool_m = 0;
     // multi-GPU exchange (collective.h)
@@ -1807,8 +1807,8 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             if (c->pool_order) (void)hipFree(c->pool_order);
             c->pool = nullptr; c->pool_keys = nullptr; c->pool_order = nullptr; c->pool_wgs = 0; c->pool_m = 0;
             HIP_TRY(c, hipMalloc((void**)&c->pool, wgs * 2u * cap * sizeof(PoolPath)));
-            HIP_TRY(c, hipMalloc((void**)&c->pool_keys, wgs * 2u * cap * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void**)&c->pool_order, wgs * cap * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void**)&c->pool_keys, wgs * 2u * cap * sizeof(uint8_t)));
+            HIP_TRY(c, hipMalloc((void**)&c->pool_order, wgs * cap * sizeof(uint16_t)));
             c->pool_wgs = wgs; c->pool_m = cap;
         }
         P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;

@@ -54,8 +54,8 @@ struct TraceParams {
     // Sorted path pools (ptx_trace_kernel_lds_sorted): per workgroup two buffers of pool_m path records, their keys, and the
     // order the current buffer is traced in.
     struct PoolPath* pool;
-    uint32_t* pool_keys;
-    uint32_t* pool_order;
+    uint8_t* pool_keys;     // < 128
+    uint16_t* pool_order;   // pool_m <= 16384
     uint32_t pool_m;
 };
 // A path between two bounces: 64 bytes = four 16-byte accesses.
