@@ -96,8 +96,10 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   kernel_family  -1 per scene (default), 0 lockstep kernels, 1 wave-scheduled kernels
  *   upload_path    -1 by scene size, 0 record re-layout on the host, 1 on the device
  *   claim_tile      0 per scene and launch; pixel jobs a wave reserves per claim: 1, or a power of two from 16 to 1024
+ *   claim_guided   -1 per scene (default), 0 every reservation is claim_tile jobs, k = 4..64: a reservation is 1/(k * waves of the
+ *                   launch) of the jobs that were left at the wave's previous one, at least claim_tile
  *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)
- *   split_small     -1 per scene (default), else: launches of up to this many samples use them, longer ones fold in the
+ *   split_small     -1 every launch (default), else: launches of up to this many samples use them, longer ones fold in the
  *                   lane (fractal scenes on the wave-scheduled kernels always use them)
  *   split_chunk     0 = bounded by the staging buffer, else samples per chunk
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes

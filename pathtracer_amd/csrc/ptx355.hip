@@ -1003,7 +1003,8 @@ struct ptx_ctx {
     uint32_t claim_tile = 1u;     // pixel jobs a wave claims at a time (1 or 64)
     uint32_t n_cu = 0;            // compute units of the device
     bool split = true;            // sample-granular jobs + fold where they pay (launch_trace)
-    uint32_t split_upto = 0x7FFFFFFFu;  // launches of up to this many samples use them (configure(): per scene)
+    uint32_t split_upto = 0x7FFFFFFFu;  // launches of up to this many samples use them (the split_small option)
+    bool plain_mesh = false;      // wave-scheduled, no marched figures, shallow tree: the scenes whose paths cost least
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
     const char* last_kernel = nullptr;  // the trace kernel of the latest launch since the scene was uploaded
     // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
@@ -1011,6 +1012,7 @@ struct ptx_ctx {
         int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
         int upload = -1;          // upload_path: -1 by size, 0 re-layout on the host, 1 on the device
         uint32_t claim_tile = 0;  // 0 per scene, 1 or 64
+        int claim_guided = -1;    // -1 per scene and launch, 0 reservations of claim_tile jobs, k >= 4: of 1/(k * waves) of the jobs left
         uint32_t split_chunk = 0; // 0 = as many samples per chunk as the staging bound allows
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
@@ -1333,6 +1335,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     if (k == "kernel_family") { if ((ok = in(-1, 1))) o.family = (int)value; }
     else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
     else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || (value >= 16 && value <= 1024 && (value & (value - 1)) == 0))) o.claim_tile = (uint32_t)value; }
+    else if (k == "claim_guided") { if ((ok = value == -1 || value == 0 || in(4, 64))) o.claim_guided = (int)value; }
     else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
     else if (k == "split_small") { if ((ok = in(-1, 0x7FFFFFFF))) o.split_upto = (int64_t)value; }
     else if (k == "split_chunk") { if ((ok = in(0, 0x7FFFFFFF))) o.split_chunk = (uint32_t)value; }
@@ -1412,11 +1415,12 @@ static int configure(ptx_ctx* c) {
     if (c->opt.shares[3]) c->share_leaf = c->opt.shares[3];
     // Sample jobs + fold with overlapping launches against whole-pixel jobs (launch_trace), ms per sample at 1080p unless said:
     // Cornell box 0.98 / 0.80 against 1.23 / 0.87 (1 / 128 samples per launch); all.yaml 2.04 / 1.75 against 2.67 / 2.47 (1 / 16);
-    // all.yaml + 10 M triangles 5.6 / 4.7 against 6.7 / 5.7 (1 / 16); fractals: see there; teapot 4K 1.46 / 1.37 / 1.40 / 1.43
-    // against 1.70 / 1.47 / 1.39 / 1.19 (1 / 2 / 4 / 16: a shallow tree without marched figures traces a sample in less time
-    // than it takes to stage and fold it).
-    const bool plain_mesh = c->sched && !sc.has_fractals && !marchers && sc.stack_entries < PT_DEEP_TREE;
-    c->split_upto = plain_mesh ? 2u : 0x7FFFFFFFu;
+    // all.yaml + 10 M triangles 5.6 / 4.7 against 6.7 / 5.7 (1 / 16); fractals: see there.  A shallow tree without marched
+    // figures traces a sample in about the time one reservation of 64 jobs takes at the launch-wide counter: there the
+    // reservations grow with the launch (launch_trace), and with them sample jobs win as well (teapot.yaml 4K, ms per launch
+    // of 4 / 16 samples: 4.4 / 15.2 against 5.0 / 16.9; iron_man.yaml 1080p, 16 / 64 samples: 3.6 / 6.0 against 8.8 / 34.3).
+    c->plain_mesh = c->sched && !sc.has_fractals && !marchers && sc.stack_entries < PT_DEEP_TREE;
+    c->split_upto = 0x7FFFFFFFu;
     if (c->opt.split_upto >= 0 && !(c->sched && sc.has_fractals)) c->split_upto = (uint32_t)c->opt.split_upto;
     c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
     if (c->opt.claim_tile) c->claim_tile = c->opt.claim_tile;
@@ -1754,6 +1758,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         }
         P.wave_state = c->wave_state;
     }
+    // Deep trees: a wave's reservations start large and shrink with the jobs left, so its lanes stay on neighbouring pixels for
+    // longer while the launch still ends evenly (all.yaml + 10 M triangles, 8 samples per launch: 36.6 -> 36.2 ms; shallow meshes,
+    // whose pixels differ a hundredfold in cost, lose up to half with reservations of thousands of jobs).
+    const uint32_t guided_k = c->opt.claim_guided >= 0 ? (uint32_t)c->opt.claim_guided
+                              : (sched && !frac && c->sc.stack_entries >= PT_DEEP_TREE ? 8u : 0u);
     if (claim) {
         P.job_counter = fixed ? (uint32_t*)c->static_scratch : (uint32_t*)&c->stats[15];
         P.total_jobs = P.n_blocks * 256u;
@@ -1766,6 +1775,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         // 130 k atomics on one address (teapot 4K, one sample per launch: 2.1 ms, 1.7 ms with 128 pixels per claim; longer
         // launches and smaller frames are 3-6 % faster with 64).
         if (!c->opt.claim_tile && sched && !frac && n <= 2u && P.n_blocks >= 16384u) P.claim_tile = 128u;
+        P.claim_div = guided_k && P.claim_tile > 1u ? guided_k * (uint32_t)waves : 0u;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
         if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
@@ -1861,6 +1871,16 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         }
         P.split_n = m; P.total_jobs = P.n_blocks * 256u * m;
         if (!c->opt.claim_tile) P.claim_tile = !frac ? (P.n_blocks >= 16384u ? 128u : 64u) : (m >= 64u ? 256u : 128u);
+        // Shallow meshes finish 8 G paths a second and more: 64 jobs per reservation is more reservations than the counter serves
+        // (one device atomic on one address: about 10 ns), while a wave that reserves 512 jobs at the end of a short launch keeps
+        // the launch waiting.  About 49 k reservations per launch, 64 to 512 jobs each -- measured at 1080p, ms per launch of
+        // 1 / 2 / 4 / 8 / 16 / 64 samples with 64 jobs: 0.9 / 1.3 / 2.3 / 3.6 / 7.0 / 27.6, 128: 0.9 / 1.0 / 1.8 / 2.7 / 5.2 / 19.5,
+        // 256: 1.2 / 1.3 / 1.8 / 2.3 / 4.3 / 16.1, 512: 1.6 / 1.9 / 2.3 / 2.7 / 4.0 / 14.8 (teapot.yaml; iron_man.yaml and car.yaml alike).
+        if (!c->opt.claim_tile && c->plain_mesh && sched) {
+            const uint32_t per = (P.total_jobs / 49152u + 63u) & ~63u;
+            P.claim_tile = per < 64u ? 64u : (per > 512u ? 512u : per);
+        }
+        P.claim_div = guided_k && P.claim_tile > 1u ? guided_k * (uint32_t)waves : 0u;
         ptx_ctx::Flight& f = c->flights[c->flight_seq % depth];
         const uint32_t slot = (uint32_t)(&f - c->flights);
         if (!f.stream) {

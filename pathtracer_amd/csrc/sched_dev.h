@@ -40,6 +40,7 @@ struct TraceParams {
     uint32_t* job_counter;  // next unclaimed 64-pixel tile of jobs (launch-wide)
     uint32_t claim_tile;    // jobs a wave reserves from job_counter at a time: 64, or 1 (just what its lanes need at that moment)
     uint32_t total_jobs;    // n_blocks * 256
+    uint32_t claim_div;     // 0, or: a reservation is 1/claim_div of the jobs that were left at the wave's previous one (at least claim_tile)
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
     uint32_t walk_single;   // scheduled kernels, WALK mode: 0 a step walks to a leaf primitive and tests it; 1 a step is one node visit and
                             // lanes at leaf primitives wait in LS_LEAF (deep trees); 2 a step walks to a leaf primitive, tests wait in LS_LEAF
@@ -513,7 +514,12 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
         return next + rank;
     }
     const uint32_t want = cnt - avail;
-    const uint32_t chunk = want > P.claim_tile ? want : P.claim_tile;
+    uint32_t chunk = P.claim_tile;
+    if (P.claim_div) {  // `end` is where the counter stood after this wave's previous reservation
+        const uint32_t share = ((P.total_jobs - (end < P.total_jobs ? end : P.total_jobs)) / P.claim_div) & ~63u;
+        chunk = share > chunk ? share : chunk;
+    }
+    chunk = want > chunk ? want : chunk;
     uint32_t base = 0u;
     if (lane == leader) base = atomicAdd(P.job_counter, chunk);
     base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);

@@ -493,3 +493,29 @@ def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w,
         assert same_bits(r[0], ref[0]) == 0 and same_bits(r[1], ref[1]) == 0, key
         assert (r[2] == ref[2]).all() and (r[3] == ref[3]).all() and r[4] == ref[4], key
     sc.upload_to(pt)  # leave the context with the default choice
+
+
+@pytest.mark.parametrize("name,w,h,n", [("teapot", 320, 180, 8), ("all", 192, 108, 6), ("fractals", 64, 36, 4)])
+def test_reservation_sizes_do_not_change_the_frame(pt, name, w, h, n):
+    """How many jobs a wave reserves at a time -- fixed sizes from 16 to 1024, or a share of the jobs left that shrinks as the
+    launch goes on -- decides only which lane traces which sample: whole-pixel and sample jobs, every setting, same frame."""
+    sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
+    cam = sc.camera(w, h)
+    results = {}
+    for split in (1, 0):
+        for opts in ({}, dict(claim_tile=16), dict(claim_tile=1024), dict(claim_guided=4), dict(claim_guided=64),
+                     dict(claim_guided=8, claim_tile=256), dict(claim_guided=0, claim_tile=128)):
+            pt.reset_options()
+            pt.set_options(kernel_family=1, split_samples=split, **opts)
+            sc.upload_to(pt)
+            assert "sched" in pt.kernel_name()
+            pt.resize(w, h)
+            pt.trace_n(cam, 0, 1, n)
+            pt.trace_n(cam, n, n + 1, 2)
+            st = pt.stats()
+            results[(split, tuple(sorted(opts.items())))] = (pt.read_accum(), pt.read_primary_ids(), (st["paths"], st["bounces"], st["shadow_rays"]))
+    pt.reset_options()
+    ref = results[(0, ())]
+    for key, r in results.items():
+        assert same_bits(r[0], ref[0]) == 0 and (r[1] == ref[1]).all() and r[2] == ref[2], key
+    sc.upload_to(pt)
