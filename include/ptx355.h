@@ -98,6 +98,9 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   claim_tile      0 per scene and launch; pixel jobs a wave reserves per claim: 1, or a power of two from 16 to 1024
  *   claim_guided   -1 per scene (default), 0 every reservation is claim_tile jobs, k = 4..64: a reservation is 1/(k * waves of the
  *                   launch) of the jobs that were left at the wave's previous one, at least claim_tile
+ *   claim_paced    -1 per scene (default), 0 off, m = 1..64: a wave doubles or halves its reservations (64 to 512 jobs) so that they
+ *                   come about m * waves * 10 ns apart
+ *   claim_cap      with paced reservations: -1 = 8 (default), 0 none, k: at most 1/(k * waves) of the jobs left per reservation
  *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)
  *   split_small     -1 every launch (default), else: launches of up to this many samples use them, longer ones fold in the
  *                   lane (fractal scenes on the wave-scheduled kernels always use them)

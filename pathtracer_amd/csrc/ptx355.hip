@@ -1012,6 +1012,8 @@ struct ptx_ctx {
         int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
         int upload = -1;          // upload_path: -1 by size, 0 re-layout on the host, 1 on the device
         uint32_t claim_tile = 0;  // 0 per scene, 1 or 64
+        int claim_paced = -1;     // -1 per scene and launch, 0 off, m: a wave's reservations are sized to come m * waves * 10 ns apart
+        int claim_cap = -1;       // with claim_paced: -1 = 8, 0 none, k: a reservation is at most 1/(k * waves) of the jobs left
         int claim_guided = -1;    // -1 per scene and launch, 0 reservations of claim_tile jobs, k >= 4: of 1/(k * waves) of the jobs left
         uint32_t split_chunk = 0; // 0 = as many samples per chunk as the staging bound allows
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
@@ -1105,6 +1107,12 @@ void free_frame(ptx_ctx* c) {
         f.staging = nullptr; f.staging_n = 0;
     }
     c->order_dirty = true;
+}
+
+static uint32_t log2_ceil(size_t v) {
+    uint32_t s = 0;
+    while (((size_t)1 << s) < v) s++;
+    return s;
 }
 
 // Makes room for the deep stack entries of `waves` waves (only scenes whose tree is deeper than PT_LDS_STACK
@@ -1336,6 +1344,8 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
     else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || (value >= 16 && value <= 1024 && (value & (value - 1)) == 0))) o.claim_tile = (uint32_t)value; }
     else if (k == "claim_guided") { if ((ok = value == -1 || value == 0 || in(4, 64))) o.claim_guided = (int)value; }
+    else if (k == "claim_paced") { if ((ok = in(-1, 64))) o.claim_paced = (int)value; }
+    else if (k == "claim_cap") { if ((ok = in(-1, 64))) o.claim_cap = (int)value; }
     else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
     else if (k == "split_small") { if ((ok = in(-1, 0x7FFFFFFF))) o.split_upto = (int64_t)value; }
     else if (k == "split_chunk") { if ((ok = in(0, 0x7FFFFFFF))) o.split_chunk = (uint32_t)value; }
@@ -1763,6 +1773,14 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // whose pixels differ a hundredfold in cost, lose up to half with reservations of thousands of jobs).
     const uint32_t guided_k = c->opt.claim_guided >= 0 ? (uint32_t)c->opt.claim_guided
                               : (sched && !frac && c->sc.stack_entries >= PT_DEEP_TREE ? 8u : 0u);
+    // The lockstep kernels with the scene in LDS, lane-owned paths (launches of up to four samples): half of the reference's
+    // scenes finish a path in less time than its share of a 64-job reservation takes at the counter (4.5 G paths/s whatever the
+    // scene).  There a wave paces itself: reservations used up in under 2/3 of 4 * waves * 10 ns double (up to 512 jobs), never
+    // beyond 1/(8 * waves) of the jobs left.  1080p, G paths/s at 4 samples per launch, in turn / back to back: test.yaml 4.1 / 6.2
+    // -> 5.4 / 8.1, aelita.yaml 4.1 / 6.4 -> 4.8 / 7.4, earth.yaml 4.0 / 5.6 -> 4.3 / 5.9, Cornell box and rings.yaml unchanged.
+    // A looser cap (1/(2 * waves)) reaches 9.2 / 16.3 on test.yaml and halves rings.yaml, whose pixels differ most in cost.
+    const uint32_t paced_m = c->opt.claim_paced >= 0 ? (uint32_t)c->opt.claim_paced : (!sched && !frac && c->sc.lds_scene_bytes > 0u ? 4u : 0u);
+    const uint32_t paced_cap = c->opt.claim_cap >= 0 ? (uint32_t)c->opt.claim_cap : 8u;
     if (claim) {
         P.job_counter = fixed ? (uint32_t*)c->static_scratch : (uint32_t*)&c->stats[15];
         P.total_jobs = P.n_blocks * 256u;
@@ -1775,7 +1793,9 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         // 130 k atomics on one address (teapot 4K, one sample per launch: 2.1 ms, 1.7 ms with 128 pixels per claim; longer
         // launches and smaller frames are 3-6 % faster with 64).
         if (!c->opt.claim_tile && sched && !frac && n <= 2u && P.n_blocks >= 16384u) P.claim_tile = 128u;
-        P.claim_div = guided_k && P.claim_tile > 1u ? guided_k * (uint32_t)waves : 0u;
+        P.claim_shift = guided_k && P.claim_tile > 1u ? log2_ceil(guided_k * waves) : 0u;
+        P.claim_period = paced_m && P.claim_tile > 1u ? paced_m * (uint32_t)waves : 0u;
+        P.claim_cap_shift = paced_cap ? log2_ceil(paced_cap * waves) + 6u : 0u;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
         if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
@@ -1880,7 +1900,8 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             const uint32_t per = (P.total_jobs / 49152u + 63u) & ~63u;
             P.claim_tile = per < 64u ? 64u : (per > 512u ? 512u : per);
         }
-        P.claim_div = guided_k && P.claim_tile > 1u ? guided_k * (uint32_t)waves : 0u;
+        P.claim_shift = guided_k && P.claim_tile > 1u ? log2_ceil(guided_k * waves) : 0u;
+        P.claim_period = paced_m && P.claim_tile > 1u ? paced_m * (uint32_t)waves : 0u;
         ptx_ctx::Flight& f = c->flights[c->flight_seq % depth];
         const uint32_t slot = (uint32_t)(&f - c->flights);
         if (!f.stream) {

@@ -40,7 +40,9 @@ struct TraceParams {
     uint32_t* job_counter;  // next unclaimed 64-pixel tile of jobs (launch-wide)
     uint32_t claim_tile;    // jobs a wave reserves from job_counter at a time: 64, or 1 (just what its lanes need at that moment)
     uint32_t total_jobs;    // n_blocks * 256
-    uint32_t claim_div;     // 0, or: a reservation is 1/claim_div of the jobs that were left at the wave's previous one (at least claim_tile)
+    uint32_t claim_shift;   // 0, or: a reservation is the jobs that were left at the wave's previous one >> claim_shift (at least claim_tile)
+    uint32_t claim_period;  // 0, or: a wave sizes its reservations (64 to 512 jobs) so that they come about this many 10 ns ticks apart
+    uint32_t claim_cap_shift; // with claim_period: 0, or a reservation is at most (jobs left >> claim_cap_shift) * 64 (at least 64)
     uint32_t share_walk, share_post, share_march;  // scheduled kernels: a state is served from 1/share of the live lanes
     uint32_t walk_single;   // scheduled kernels, WALK mode: 0 a step walks to a leaf primitive and tests it; 1 a step is one node visit and
                             // lanes at leaf primitives wait in LS_LEAF (deep trees); 2 a step walks to a leaf primitive, tests wait in LS_LEAF
@@ -476,7 +478,7 @@ PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J, bool spli
 // wave's program order -- through relaxed device-scope atomics, so that neither the compiler nor the per-CU cache keeps an
 // earlier value.  (The trace kernels use every byte of LDS that four workgroups per CU leave: 48 bytes of LDS for this
 // state cost the global-scene kernels a workgroup per CU, 12 % on the 10 M-triangle scene.)
-struct WaveState { uint32_t next, end, paths, pad; };
+struct WaveState { uint32_t next, end, paths, pad; };  // pad: the paced reservations' record (claim_jobs)
 PT_DEV WaveState* wave_state(const TraceParams& P) { return P.wave_state + (size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + (threadIdx.x >> 6); }
 PT_DEV void wave_claim_init(const TraceParams& P) {
     if ((threadIdx.x & 63u) == 0u) {
@@ -484,6 +486,7 @@ PT_DEV void wave_claim_init(const TraceParams& P) {
         __hip_atomic_store(&ws->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ws->end, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ws->paths, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->pad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // One job number for every lane that calls (the lanes of a wave whose pixels finished together).  Jobs come from the wave's
@@ -506,8 +509,9 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
         return (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) + rank;
     }
     WaveState* ws = wave_state(P);
-    const uint32_t next = __hip_atomic_load(&ws->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t end = __hip_atomic_load(&ws->end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the record is the wave's own: every lane reads the same words, kept in scalar registers from here on
+    const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const uint32_t avail = end - next;
     if (cnt <= avail) {
         if (lane == leader) __hip_atomic_store(&ws->next, next + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -515,9 +519,36 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
     }
     const uint32_t want = cnt - avail;
     uint32_t chunk = P.claim_tile;
-    if (P.claim_div) {  // `end` is where the counter stood after this wave's previous reservation
-        const uint32_t share = ((P.total_jobs - (end < P.total_jobs ? end : P.total_jobs)) / P.claim_div) & ~63u;
-        chunk = share > chunk ? share : chunk;
+    if (P.claim_period | P.claim_shift) {
+        // `end` is where the counter stood after this wave's previous reservation.  Scalar integer work only (shifts and compares):
+        // the kernels have no vector register to spare here.
+        const uint32_t left = P.total_jobs - (end < P.total_jobs ? end : P.total_jobs);
+        if (P.claim_period) {
+            // The wave's own pace sets the size: the record keeps when its previous reservation was made (24 bits of the 100 MHz
+            // clock, which wrap after 168 ms) and how large it was (in 64 jobs, the top byte).  Used up in under 2/3 of
+            // claim_period: the next is twice as large; it lasted over 3/2: half; 64 to 512 jobs.
+            const uint32_t now = (uint32_t)wall_clock64() & 0xFFFFFFu;
+            const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            uint32_t units = rec >> 24;
+            if (units) {
+                const uint32_t dt = (now - rec) & 0xFFFFFFu;
+                if (dt * 3u < P.claim_period * 2u) units <<= 1;
+                else if (dt * 2u > P.claim_period * 3u) units >>= 1;
+                units = units > 8u ? 8u : units;
+            } else {
+                units = chunk >> 6;
+            }
+            if (P.claim_cap_shift) {
+                const uint32_t cap = left >> P.claim_cap_shift;
+                units = units > cap ? cap : units;
+            }
+            units = units < 1u ? 1u : units;
+            chunk = units << 6;
+            if (lane == leader) __hip_atomic_store(&ws->pad, units << 24 | now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const uint32_t share = (left >> P.claim_shift) & ~63u;
+            chunk = share > chunk ? share : chunk;
+        }
     }
     chunk = want > chunk ? want : chunk;
     uint32_t base = 0u;

@@ -495,20 +495,23 @@ def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w,
     sc.upload_to(pt)  # leave the context with the default choice
 
 
-@pytest.mark.parametrize("name,w,h,n", [("teapot", 320, 180, 8), ("all", 192, 108, 6), ("fractals", 64, 36, 4)])
-def test_reservation_sizes_do_not_change_the_frame(pt, name, w, h, n):
-    """How many jobs a wave reserves at a time -- fixed sizes from 16 to 1024, or a share of the jobs left that shrinks as the
-    launch goes on -- decides only which lane traces which sample: whole-pixel and sample jobs, every setting, same frame."""
+@pytest.mark.parametrize("name,w,h,n,family", [("teapot", 320, 180, 8, 1), ("all", 192, 108, 6, 1), ("fractals", 64, 36, 4, 1),
+                                               ("cornell_box", 320, 180, 4, 0), ("rings", 640, 360, 3, 0)])
+def test_reservation_sizes_do_not_change_the_frame(pt, name, w, h, n, family):
+    """How many jobs a wave reserves at a time -- fixed sizes from 16 to 1024, a share of the jobs left that shrinks as the
+    launch goes on, or sizes the wave sets by its own pace -- decides only which lane traces which sample: whole-pixel and
+    sample jobs, both kernel families, every setting, same frame."""
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
     cam = sc.camera(w, h)
     results = {}
     for split in (1, 0):
         for opts in ({}, dict(claim_tile=16), dict(claim_tile=1024), dict(claim_guided=4), dict(claim_guided=64),
-                     dict(claim_guided=8, claim_tile=256), dict(claim_guided=0, claim_tile=128)):
+                     dict(claim_guided=8, claim_tile=256), dict(claim_guided=0, claim_tile=128), dict(claim_paced=0, claim_guided=0),
+                     dict(claim_paced=1, claim_cap=0), dict(claim_paced=64, claim_cap=1), dict(claim_paced=4, claim_tile=512)):
             pt.reset_options()
-            pt.set_options(kernel_family=1, split_samples=split, **opts)
+            pt.set_options(kernel_family=family, split_samples=split, sorted_pool=0, **opts)
             sc.upload_to(pt)
-            assert "sched" in pt.kernel_name()
+            assert ("sched" in pt.kernel_name()) == (family == 1)
             pt.resize(w, h)
             pt.trace_n(cam, 0, 1, n)
             pt.trace_n(cam, n, n + 1, 2)

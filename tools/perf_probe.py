@@ -47,6 +47,19 @@ for name, w, h, ns in CASES:
             pt.sync()
             t, _ = pt.kernel_time()
             ms = min(ms, t) if rep else ms
+        if os.environ.get("PROBE_REPEAT"):  # K launches back to back (short ones overlap), wall time per launch
+            k = int(os.environ["PROBE_REPEAT"])
+            pt.clear()
+            pt.sync()
+            t0 = time.perf_counter()
+            for i in range(k):
+                pt.trace_n(cam, i * n, i * n + 1, n)
+            pt.sync()
+            ms = (time.perf_counter() - t0) * 1e3 / k
+            pt.kernel_time()
+            pt.clear()
+            pt.trace_n(cam, 0, 1, n)
+            pt.sync()
         st = pt.stats()
         print(f"{name} {w}x{h} n={n}: kernel {ms:.1f} ms  {w * h * n / ms / 1e3:.1f} Mpaths/s  {st['bounces'] / ms / 1e6:.3f} Gpath-bounce/s  "
-              f"bounces/path {st['bounces'] / st['paths']:.2f} shadow/path {st['shadow_rays'] / st['paths']:.2f}", flush=True)
+              f"bounces/path {st['bounces'] / st['paths']:.2f} shadow/path {st['shadow_rays'] / st['paths']:.2f}  {pt.kernel_name()}", flush=True)
