@@ -47,9 +47,10 @@
 // from module load to process exit; every call on a device shares it.
 #define PTX_FLIGHTS 8  // launches of sample-granular jobs that may be in flight at once (their staging buffers: 8 GiB together at most)
 #define PTX_FLIGHTS_DEFAULT 6u
+#define PTX_CLAIM_RANGES 16  // job counters of a launch at most
 #define PTX_STATIC_MAX_WAVES 4096u
 #define PTX_STATIC_WAVES_OFFSET 256u
-#define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_WAVES_OFFSET + PTX_STATIC_MAX_WAVES * 16u)
+#define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_WAVES_OFFSET + PTX_STATIC_MAX_WAVES * 32u)  // sizeof(WaveState)
 #define PTX_STATIC_BYTES (PTX_STATIC_SPILL_OFFSET + (size_t)PTX_STATIC_MAX_WAVES * (31u - PT_LDS_STACK) * 64u * 8u)
 static __device__ __align__(256) unsigned char ptx_static_scratch[PTX_STATIC_BYTES];
 
@@ -80,7 +81,7 @@ PT_DEV void copy_to_lds(void* dst, const void* src, uint32_t bytes) {
 // LDS read (~100 cycles) instead of a dependent L1/L2 round trip, which is what the traversal waits on.
 // CLAIM: the grid is sized to the GPU and a lane whose pixel has all its samples claims the next unclaimed
 // pixel (job_pixel / claim_pixel in sched_dev.h) instead of idling until the slowest pixel of its wave is done.
-template <bool LDS_SCENE, bool FRAC, bool CLAIM>
+template <bool LDS_SCENE, bool FRAC, bool CLAIM, int CM = FRAC ? CLAIM_PLAIN : CLAIM_PACED>
 PT_DEV void trace_body(const TraceParams& P) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -117,14 +118,14 @@ PT_DEV void trace_body(const TraceParams& P) {
     PixelJob J;
     bool active = false;
     const bool split = CLAIM && P.split_n > 0u;  // jobs are single samples, staged for ptx_fold_kernel (TraceParams::split_n)
-    wave_claim_init(P);
+    wave_claim_init(P, CM == CLAIM_RANGED || CM == CLAIM_PACED);
     px_f[3 * 64] = 0.0f; px_f[4 * 64] = 0.0f; px_f[5 * 64] = 0.0f;
     px_u[6 * 64] = 0u;            // k: samples of the current pixel finished
     px_u[7 * 64] = 0u;            // path-bounces
     px_u[8 * 64] = 0xFFFFFFFFu;   // primary hit of the latest sample
     if (P.n > 0u) {
         if (CLAIM) {
-            active = claim_pixel(P, job, true, px_f, J, split);
+            active = claim_pixel<CM>(P, job, true, px_f, J, split);
         } else if (job_pixel(P, job, J)) {
             active = true;
             float4 a = P.accum[J.pix];
@@ -171,7 +172,7 @@ PT_DEV void trace_body(const TraceParams& P) {
             px_u[7 * 64] += local_bounces;
             local_bounces = 0u;
             add_paths(P, 1u);
-            active = claim_pixel(P, job, false, px_f, J, true);
+            active = claim_pixel<CM>(P, job, false, px_f, J, true);
             px_u[8 * 64] = 0xFFFFFFFFu;
             if (active) {
                 ps.rng = pcg_hash(J.px + J.py * 65536u + (P.first_frame + J.k) * 16777259u);
@@ -212,7 +213,7 @@ PT_DEV void trace_body(const TraceParams& P) {
                 P.out_rgba8[J.pix] = tonemap_rgba8(P.cam, nm);
                 P.primary_ids[J.pix] = px_u[8 * 64];
                 add_paths(P, k_next);
-                active = CLAIM && claim_pixel(P, job, false, px_f, J);
+                active = CLAIM && claim_pixel<CM>(P, job, false, px_f, J);
                 px_u[8 * 64] = 0xFFFFFFFFu;
                 k_next = 0u;
             }
@@ -561,18 +562,18 @@ PT_DEV void sched_body(const TraceParams& P) {
     tv.have = false; tv.shadow = false;
     tv.m.t = 0.0f; tv.m.prev_d = 0.0f; tv.m.max_t = 0.0f; tv.m.i = 0u;
     uint32_t S = LS_IDLE;
-    wave_claim_init(P);
+    wave_claim_init(P, false);
     uint32_t job = blockIdx.x * PTX_BLOCK + threadIdx.x;  // the first job of every lane; the counter starts behind them
     // jobs are single samples (TraceParams::split_n): the fractal kernels decide per launch, the others are compiled for one
     // form or the other (the unused form's code cost the teapot 2.5 %)
     const bool split = SAMPLES && (!FRAC || P.split_n > 0u);
     if (P.n > 0u) {
         PixelJob J;
-        if (claim_pixel(P, job, true, px_f, J, split)) {
+        if (claim_pixel<FRAC ? CLAIM_PLAIN : CLAIM_GUIDED>(P, job, true, px_f, J, split)) {
             Ray r0;
             r0.o = v3(0.0f, 0.0f, 0.0f);
             r0.d = v3(0.0f, 0.0f, 1.0f);
-            S = next_path(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u, split);
+            S = next_path<FRAC ? CLAIM_PLAIN : CLAIM_GUIDED>(sc, P, tv, park, px_f, job, true, false, r0, v3(1.0f, 1.0f, 1.0f), v3(0.0f, 0.0f, 0.0f), 0u, 0u, split);
         }
     }
     if (PARK_JOB) { px_u[4 * 64] = job; px_u[5 * 64] = 0u; }
@@ -797,6 +798,7 @@ extern "C" __global__ void __launch_bounds__(256) ptx_fold_kernel(const TracePar
 // Without them the kernel fits 128 VGPRs (4 waves per SIMD); with them 3 waves.
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel(const TraceParams P) { trace_body<false, false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds(const TraceParams P) { trace_body<true, false, PTX_CLAIM_LDS>(P); }
+extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds_ranged(const TraceParams P) { trace_body<true, false, PTX_CLAIM_LDS, CLAIM_RANGED>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_lds_sorted(const TraceParams P) { sorted_body<true, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 4) ptx_trace_kernel_sorted(const TraceParams P) { sorted_body<false, false>(P); }
 extern "C" __global__ void __launch_bounds__(PTX_BLOCK, 3) ptx_trace_kernel_frac(const TraceParams P) { trace_body<false, true, false>(P); }
@@ -1012,6 +1014,7 @@ struct ptx_ctx {
         int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
         int upload = -1;          // upload_path: -1 by size, 0 re-layout on the host, 1 on the device
         uint32_t claim_tile = 0;  // 0 per scene, 1 or 64
+        uint32_t claim_ranges = 0; // 0 per scene, else 1..16: job counters the reservations are spread over
         int claim_paced = -1;     // -1 per scene and launch, 0 off, m: a wave's reservations are sized to come m * waves * 10 ns apart
         int claim_cap = -1;       // with claim_paced: -1 = 8, 0 none, k: a reservation is at most 1/(k * waves) of the jobs left
         int claim_guided = -1;    // -1 per scene and launch, 0 reservations of claim_tile jobs, k >= 4: of 1/(k * waves) of the jobs left
@@ -1040,7 +1043,7 @@ struct ptx_ctx {
     };
     Flight flights[PTX_FLIGHTS];
     uint32_t flight_seq = 0;
-    uint32_t* flight_counters = nullptr;  // one job counter per flight, 256 bytes apart
+    uint32_t* flight_counters = nullptr;  // PTX_CLAIM_RANGES job counters per flight and for the context's own stream, 256 bytes apart
     hipEvent_t barrier = nullptr;         // everything enqueued on `stream` by calls other than those launches, up to the last of them
     bool order_dirty = true;              // such a call has been made since `barrier` was recorded
     const void* occ_kernel = nullptr;  // the last occupancy query: kernel, LDS bytes -> resident workgroups per compute unit
@@ -1107,6 +1110,14 @@ void free_frame(ptx_ctx* c) {
         f.staging = nullptr; f.staging_n = 0;
     }
     c->order_dirty = true;
+}
+
+// Spreads the jobs behind the lanes' first ones (jobs 0 .. first - 1) over `ranges` counters.
+static void set_ranges(TraceParams& P, uint32_t ranges, uint32_t first) {
+    P.job_first = first;
+    P.claim_ranges = P.claim_tile > 1u ? ranges : 1u;
+    const uint32_t rest = P.total_jobs > first ? P.total_jobs - first : 0u;
+    P.range_len = ((rest + P.claim_ranges - 1u) / P.claim_ranges + 63u) & ~63u;
 }
 
 static uint32_t log2_ceil(size_t v) {
@@ -1344,6 +1355,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "upload_path") { if ((ok = in(-1, 1))) o.upload = (int)value; }
     else if (k == "claim_tile") { if ((ok = value == 0 || value == 1 || (value >= 16 && value <= 1024 && (value & (value - 1)) == 0))) o.claim_tile = (uint32_t)value; }
     else if (k == "claim_guided") { if ((ok = value == -1 || value == 0 || in(4, 64))) o.claim_guided = (int)value; }
+    else if (k == "claim_ranges") { if ((ok = in(0, PTX_CLAIM_RANGES))) o.claim_ranges = (uint32_t)value; }
     else if (k == "claim_paced") { if ((ok = in(-1, 64))) o.claim_paced = (int)value; }
     else if (k == "claim_cap") { if ((ok = in(-1, 64))) o.claim_cap = (int)value; }
     else if (k == "split_samples") { if ((ok = in(0, 1))) c->split = value != 0; }
@@ -1383,7 +1395,7 @@ static bool pick_sched(const DScene& sc, uint32_t type_mask, int forced) {
 typedef void (*TraceKernel)(const TraceParams);
 static const char* trace_kernel_label(TraceKernel k) {
 #define PTX_NAME(f) if (k == f) return #f;
-    PTX_NAME(ptx_trace_kernel) PTX_NAME(ptx_trace_kernel_lds) PTX_NAME(ptx_trace_kernel_lds_sorted) PTX_NAME(ptx_trace_kernel_sorted) PTX_NAME(ptx_trace_kernel_frac)
+    PTX_NAME(ptx_trace_kernel) PTX_NAME(ptx_trace_kernel_lds) PTX_NAME(ptx_trace_kernel_lds_ranged) PTX_NAME(ptx_trace_kernel_lds_sorted) PTX_NAME(ptx_trace_kernel_sorted) PTX_NAME(ptx_trace_kernel_frac)
     PTX_NAME(ptx_trace_kernel_lds_frac) PTX_NAME(ptx_sched_kernel) PTX_NAME(ptx_sched_kernel_lds) PTX_NAME(ptx_sched_kernel_samples)
     PTX_NAME(ptx_sched_kernel_lds_samples) PTX_NAME(ptx_sched_kernel_frac) PTX_NAME(ptx_sched_kernel_lds_frac)
 #undef PTX_NAME
@@ -1771,18 +1783,29 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Deep trees: a wave's reservations start large and shrink with the jobs left, so its lanes stay on neighbouring pixels for
     // longer while the launch still ends evenly (all.yaml + 10 M triangles, 8 samples per launch: 36.6 -> 36.2 ms; shallow meshes,
     // whose pixels differ a hundredfold in cost, lose up to half with reservations of thousands of jobs).
-    const uint32_t guided_k = c->opt.claim_guided >= 0 ? (uint32_t)c->opt.claim_guided
-                              : (sched && !frac && c->sc.stack_entries >= PT_DEEP_TREE ? 8u : 0u);
+    const uint32_t guided_k = !sched || frac ? 0u : (c->opt.claim_guided >= 0 ? (uint32_t)c->opt.claim_guided : (c->sc.stack_entries >= PT_DEEP_TREE ? 8u : 0u));
     // The lockstep kernels with the scene in LDS, lane-owned paths (launches of up to four samples): half of the reference's
     // scenes finish a path in less time than its share of a 64-job reservation takes at the counter (4.5 G paths/s whatever the
     // scene).  There a wave paces itself: reservations used up in under 2/3 of 4 * waves * 10 ns double (up to 512 jobs), never
     // beyond 1/(8 * waves) of the jobs left.  1080p, G paths/s at 4 samples per launch, in turn / back to back: test.yaml 4.1 / 6.2
     // -> 5.4 / 8.1, aelita.yaml 4.1 / 6.4 -> 4.8 / 7.4, earth.yaml 4.0 / 5.6 -> 4.3 / 5.9, Cornell box and rings.yaml unchanged.
     // A looser cap (1/(2 * waves)) reaches 9.2 / 16.3 on test.yaml and halves rings.yaml, whose pixels differ most in cost.
-    const uint32_t paced_m = c->opt.claim_paced >= 0 ? (uint32_t)c->opt.claim_paced : (!sched && !frac && c->sc.lds_scene_bytes > 0u ? 4u : 0u);
+    const uint32_t paced_m = sched || frac ? 0u : (c->opt.claim_paced >= 0 ? (uint32_t)c->opt.claim_paced : (c->sc.lds_scene_bytes > 0u ? 4u : 0u));
     const uint32_t paced_cap = c->opt.claim_cap >= 0 ? (uint32_t)c->opt.claim_cap : 8u;
+    // One counter hands out jobs in frame order: all waves of the GPU work on the same few rows at a time, which a deep tree in
+    // memory wants (every wave walks the same part of it).  Scenes whose paths cost little want reservations served faster than one
+    // address can (88 M a second): sixteen counters, each handing out a sixteenth of the jobs, a wave moving on when its counter runs out.
+    // Only the lockstep kernel has the registers for it, in a variant of its own (CLAIM_RANGED, sched_dev.h: its counters count
+    // from zero, the others' one counter from the first unassigned job), for scenes of a handful of figures: the Cornell box
+    // (13 figures) and rings.yaml (19) lose 3 % with sixteen counters, test.yaml (3) doubles, aelita.yaml (5) gains a fifth.
+    const uint32_t ranges_wanted = sched || frac || fixed || c->sc.lds_scene_bytes == 0u ? 1u
+                                   : (c->opt.claim_ranges ? c->opt.claim_ranges : (c->sc.nfig <= 8u ? (uint32_t)PTX_CLAIM_RANGES : 1u));
     if (claim) {
-        P.job_counter = fixed ? (uint32_t*)c->static_scratch : (uint32_t*)&c->stats[15];
+        if (!fixed && !c->flight_counters) {
+            HIP_TRY(c, hipMalloc((void**)&c->flight_counters, (PTX_FLIGHTS + 1) * PTX_CLAIM_RANGES * 256));
+            HIP_TRY(c, hipMemset(c->flight_counters, 0, (PTX_FLIGHTS + 1) * PTX_CLAIM_RANGES * 256));
+        }
+        P.job_counter = fixed ? (uint32_t*)c->static_scratch : c->flight_counters + PTX_FLIGHTS * PTX_CLAIM_RANGES * 64;
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
         // Lockstep kernels: short launches are bound by the rate of the claims (one device atomic per finished pixel and wave),
@@ -1844,6 +1867,9 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;
         kernel = c->sc.lds_scene_bytes > 0u ? ptx_trace_kernel_lds_sorted : ptx_trace_kernel_sorted;  // same LDS, four waves per SIMD
     }
+    const bool zero_based = kernel == ptx_trace_kernel_lds && ranges_wanted > 1u;
+    const uint32_t ranges = zero_based ? ranges_wanted : 1u;
+    if (zero_based) kernel = ptx_trace_kernel_lds_ranged;  // same LDS, same occupancy
     c->last_kernel = trace_kernel_label(kernel);
     uint32_t chunk = n;
     size_t frame_pixels = 0;
@@ -1867,7 +1893,6 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         if (!frac && n > 4u) depth = 1u;
         if (c->opt.flights >= 1u) depth =c->opt.flights < in_flight || c->opt.flights <= 2u ? c->opt.flights : (in_flight < 2 ? 2u : (uint32_t)in_flight);
         if (sorted) depth = 1u;  // one set of pools per context
-        if (!c->flight_counters) HIP_TRY(c, hipMalloc((void**)&c->flight_counters, PTX_FLIGHTS * 256));
         if (!c->barrier) HIP_TRY(c, hipEventCreateWithFlags(&c->barrier, hipEventDisableTiming));
     } else {
         c->order_dirty = true;
@@ -1884,7 +1909,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         P.first_frame = first_frame + done; P.first_sample = first_sample + done; P.n = m;
         if (!split) {
             P.split_n = 0u; P.total_jobs = P.n_blocks * 256u;
-            if (claim) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
+            if (claim) {
+                set_ranges(P, ranges, grid * 256u);
+                if (zero_based) HIP_TRY(c, hipMemsetAsync(P.job_counter, 0, P.claim_ranges * 256u, c->stream));
+                else HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
+            }
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
             HIP_TRY(c, hipGetLastError());
             continue;
@@ -1936,9 +1965,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         if (f.used) HIP_TRY(c, hipStreamWaitEvent(f.stream, f.folded, 0));
         P.staging = f.staging;
         P.wave_state = f.wave_state;
-        P.job_counter = c->flight_counters + slot * 64u;
+        P.job_counter = c->flight_counters + slot * (PTX_CLAIM_RANGES * 64u);
         // the lane-owned kernels start with jobs 0 .. grid * 256 - 1 in their lanes; the pools reserve every job they trace
-        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, sorted ? 0 : (int)(grid * 256u), 1, f.stream));
+        set_ranges(P, sorted ? 1u : ranges, sorted ? 0u : grid * 256u);
+        if (zero_based || sorted) HIP_TRY(c, hipMemsetAsync(P.job_counter, 0, P.claim_ranges * 256u, f.stream));
+        else HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, f.stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, f.stream, P);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(f.traced, f.stream));

@@ -40,6 +40,9 @@ struct TraceParams {
     uint32_t* job_counter;  // next unclaimed 64-pixel tile of jobs (launch-wide)
     uint32_t claim_tile;    // jobs a wave reserves from job_counter at a time: 64, or 1 (just what its lanes need at that moment)
     uint32_t total_jobs;    // n_blocks * 256
+    // The jobs behind the lanes' first ones (job_first) are reserved from claim_ranges counters, 256 bytes apart: counter r hands
+    // out jobs job_first + r * range_len .. + range_len (one address serves 88 M atomics a second, sixteen serve sixteen times as many)
+    uint32_t job_first, claim_ranges, range_len;
     uint32_t claim_shift;   // 0, or: a reservation is the jobs that were left at the wave's previous one >> claim_shift (at least claim_tile)
     uint32_t claim_period;  // 0, or: a wave sizes its reservations (64 to 512 jobs) so that they come about this many 10 ns ticks apart
     uint32_t claim_cap_shift; // with claim_period: 0, or a reservation is at most (jobs left >> claim_cap_shift) * 64 (at least 64)
@@ -473,20 +476,31 @@ PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J, bool spli
     J.pix = (size_t)J.py * P.cam.width + J.px;
     return J.tx < P.tile_w && J.ty < P.tile_h;
 }
-// A wave's claim state and path tally: one 16-byte record per wave of the grid in global memory ({next job, end} of the
+// A wave's claim state and path tally: one 32-byte record per wave of the grid in global memory ({next job, end} of the
 // jobs the wave has reserved, paths finished), which only that wave touches -- one lane writes, all its lanes read, in the
 // wave's program order -- through relaxed device-scope atomics, so that neither the compiler nor the per-CU cache keeps an
 // earlier value.  (The trace kernels use every byte of LDS that four workgroups per CU leave: 48 bytes of LDS for this
 // state cost the global-scene kernels a workgroup per CU, 12 % on the 10 M-triangle scene.)
-struct WaveState { uint32_t next, end, paths, pad; };  // pad: the paced reservations' record (claim_jobs)
+struct WaveState {
+    uint32_t next, end, paths;  // the jobs it has reserved and not handed out; paths finished
+    uint32_t pace;              // paced reservations: when the previous one was made and how large it was (claim_jobs)
+    uint32_t range;             // the counter it reserves from | how many counters it has found exhausted << 8 (all of them: no jobs left)
+    uint32_t pad[3];
+};
+static_assert(sizeof(WaveState) == 32, "WaveState");
 PT_DEV WaveState* wave_state(const TraceParams& P) { return P.wave_state + (size_t)blockIdx.x * PTX_WAVES_PER_BLOCK + (threadIdx.x >> 6); }
-PT_DEV void wave_claim_init(const TraceParams& P) {
+// `ranged`: the kernel reserves from several counters (CLAIM_RANGED, below)
+PT_DEV void wave_claim_init(const TraceParams& P, bool ranged) {
     if ((threadIdx.x & 63u) == 0u) {
         WaveState* ws = wave_state(P);
         __hip_atomic_store(&ws->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ws->end, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ws->paths, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws->pad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ranged) {
+            const uint32_t wave = blockIdx.x * PTX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+            __hip_atomic_store(&ws->pace, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws->range, P.claim_ranges > 1u ? wave % P.claim_ranges : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 // One job number for every lane that calls (the lanes of a wave whose pixels finished together).  Jobs come from the wave's
@@ -498,6 +512,40 @@ PT_DEV void wave_claim_init(const TraceParams& P) {
 // Cornell box.  Otherwise a range is claim_tile jobs (64: one 8x8 quadrant, so the lanes of a wave stay on neighbouring
 // pixels, which serves meshes and the Moebius marcher: +4 % / +18 %).  Ranges that shrink with the work left, to even out the
 // end of the launch, measured slower (Cornell box, one sample per launch: 1.5 ms against 1.3).
+#define PT_JOB_RETRY 0xFFFFFFFFu  // claim_jobs: the counter ran out under this lane's feet, there may be jobs at another
+// MODE: what the kernel is compiled for (each costs registers: the wave-scheduled kernels have none to spare, and the lockstep
+// kernel's code for the Cornell box is sensitive to all of it) --
+// CLAIM_PLAIN   one counter, which starts at the first unassigned job, reservations of claim_tile jobs (the fractal kernels);
+// CLAIM_GUIDED  the same with sizes by the jobs left (claim_shift; the other wave-scheduled kernels);
+// CLAIM_PACED   the same with sizes by the wave's pace (claim_period; the lockstep kernels);
+// CLAIM_RANGED  several counters, which start at zero, sizes by the wave's pace (the lockstep kernel for scenes of a few figures).
+// The host sets the parameters to match (launch_trace).
+enum : int { CLAIM_PLAIN = 0, CLAIM_GUIDED = 1, CLAIM_PACED = 2, CLAIM_RANGED = 3 };
+// The wave's own pace sets the size of its reservations: its record keeps when the previous one was made (24 bits of the
+// 100 MHz clock, which wrap after 168 ms) and how large it was (in 64 jobs, the top byte).  Used up in under 2/3 of claim_period:
+// the next is twice as large; it lasted over 3/2: half; 64 to 512 jobs, and no more than the jobs left >> claim_cap_shift.
+// Scalar integer work only (shifts and compares): the kernels have no vector register to spare here.
+PT_DEV uint32_t paced_size(const TraceParams& P, WaveState* ws, uint32_t first_size, uint32_t left, bool leader) {
+    const uint32_t now = (uint32_t)wall_clock64() & 0xFFFFFFu;
+    const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    uint32_t units = rec >> 24;
+    if (units) {
+        const uint32_t dt = (now - rec) & 0xFFFFFFu;
+        if (dt * 3u < P.claim_period * 2u) units <<= 1;
+        else if (dt * 2u > P.claim_period * 3u) units >>= 1;
+        units = units > 8u ? 8u : units;
+    } else {
+        units = first_size >> 6;
+    }
+    if (P.claim_cap_shift) {
+        const uint32_t cap = left >> P.claim_cap_shift;
+        units = units > cap ? cap : units;
+    }
+    units = units < 1u ? 1u : units;
+    if (leader) __hip_atomic_store(&ws->pace, units << 24 | now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return units << 6;
+}
+template <int MODE>
 PT_DEV uint32_t claim_jobs(const TraceParams& P) {
     const unsigned long long need = __ballot(true);
     const uint32_t lane = threadIdx.x & 63u;
@@ -506,7 +554,7 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
     if (P.claim_tile <= 1u) {  // no reserve to keep: the wave's state is not touched
         uint32_t base = 0u;
         if (lane == leader) base = atomicAdd(P.job_counter, cnt);
-        return (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) + rank;
+        return (MODE == CLAIM_RANGED ? P.job_first : 0u) + (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) + rank;
     }
     WaveState* ws = wave_state(P);
     // the record is the wave's own: every lane reads the same words, kept in scalar registers from here on
@@ -519,53 +567,72 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
     }
     const uint32_t want = cnt - avail;
     uint32_t chunk = P.claim_tile;
-    if (P.claim_period | P.claim_shift) {
-        // `end` is where the counter stood after this wave's previous reservation.  Scalar integer work only (shifts and compares):
-        // the kernels have no vector register to spare here.
-        const uint32_t left = P.total_jobs - (end < P.total_jobs ? end : P.total_jobs);
-        if (P.claim_period) {
-            // The wave's own pace sets the size: the record keeps when its previous reservation was made (24 bits of the 100 MHz
-            // clock, which wrap after 168 ms) and how large it was (in 64 jobs, the top byte).  Used up in under 2/3 of
-            // claim_period: the next is twice as large; it lasted over 3/2: half; 64 to 512 jobs.
-            const uint32_t now = (uint32_t)wall_clock64() & 0xFFFFFFu;
-            const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            uint32_t units = rec >> 24;
-            if (units) {
-                const uint32_t dt = (now - rec) & 0xFFFFFFu;
-                if (dt * 3u < P.claim_period * 2u) units <<= 1;
-                else if (dt * 2u > P.claim_period * 3u) units >>= 1;
-                units = units > 8u ? 8u : units;
-            } else {
-                units = chunk >> 6;
-            }
-            if (P.claim_cap_shift) {
-                const uint32_t cap = left >> P.claim_cap_shift;
-                units = units > cap ? cap : units;
-            }
-            units = units < 1u ? 1u : units;
-            chunk = units << 6;
-            if (lane == leader) __hip_atomic_store(&ws->pad, units << 24 | now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const uint32_t share = (left >> P.claim_shift) & ~63u;
+    if (MODE != CLAIM_RANGED) {
+        // `end` is where the counter stood after this wave's previous reservation
+        if (MODE == CLAIM_GUIDED && P.claim_shift) {
+            const uint32_t share = ((P.total_jobs - (end < P.total_jobs ? end : P.total_jobs)) >> P.claim_shift) & ~63u;
             chunk = share > chunk ? share : chunk;
         }
+        if (MODE == CLAIM_PACED && P.claim_period) chunk = paced_size(P, ws, chunk, P.total_jobs - (end < P.total_jobs ? end : P.total_jobs), lane == leader);
+        chunk = want > chunk ? want : chunk;
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(P.job_counter, chunk);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (lane == leader) {
+            __hip_atomic_store(&ws->next, base + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws->end, base + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return rank < avail ? next + rank : base + (rank - avail);
+    }
+    // which counter, and how many the wave has found exhausted: one word
+    const uint32_t rt = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    uint32_t r = rt & 0xFFu, tried = rt >> 8;
+    if (P.claim_period) {
+        // the jobs left, estimated from where this wave's counter stood after its previous reservation (`end`): the other
+        // counters stand about as far into their ranges
+        uint32_t r_end = P.job_first + (r + 1u) * P.range_len;
+        r_end = r_end < P.total_jobs ? r_end : P.total_jobs;
+        uint32_t left = (end == 0u ? P.range_len : (end < r_end ? r_end - end : 0u)) * P.claim_ranges;
+        left = left < P.total_jobs ? left : P.total_jobs;
+        chunk = paced_size(P, ws, chunk, left, lane == leader);
     }
     chunk = want > chunk ? want : chunk;
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(P.job_counter, chunk);
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-    if (lane == leader) {
-        __hip_atomic_store(&ws->next, base + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws->end, base + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // One device atomic on the wave's current counter.  A counter that has run out sends the wave on to the next (the lanes
+    // without a job ask again: PT_JOB_RETRY); a wave that has found every counter exhausted asks no more.
+    uint32_t base = P.total_jobs, got = 0u;
+    if (tried < P.claim_ranges) {
+        uint32_t local = 0u;
+        if (lane == leader) local = atomicAdd(P.job_counter + r * 64u, chunk);
+        local = (uint32_t)__builtin_amdgcn_readlane((int)local, (int)leader);
+        const uint32_t start = P.job_first + r * P.range_len;
+        uint32_t r_end = start + P.range_len;
+        r_end = r_end < P.total_jobs ? r_end : P.total_jobs;
+        if (local < P.range_len && start + local < r_end) {
+            base = start + local;
+            got = r_end - base < chunk ? r_end - base : chunk;
+        } else {
+            r = r + 1u == P.claim_ranges ? 0u : r + 1u;
+            tried += 1u;
+        }
+        if (lane == leader) {
+            __hip_atomic_store(&ws->next, base + (want < got ? want : got), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws->end, base + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws->range, r | tried << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    return rank < avail ? next + rank : base + (rank - avail);
+    if (rank < avail) return next + rank;
+    const uint32_t k = rank - avail;
+    if (k < got) return base + k;
+    return tried < P.claim_ranges ? PT_JOB_RETRY : P.total_jobs;
 }
 // Claims jobs until one lies inside the tile; loads that pixel's accumulator into the lane's LDS slots.
+template <int MODE>
 PT_DEV bool claim_pixel(const TraceParams& P, uint32_t& job, bool have_candidate, float* px_f, PixelJob& J, bool split = false) {
     uint32_t* px_u = (uint32_t*)px_f;
     for (;;) {
-        if (!have_candidate) job = claim_jobs(P);
+        if (!have_candidate) job = claim_jobs<MODE>(P);
         have_candidate = false;
+        if (MODE == CLAIM_RANGED && job == PT_JOB_RETRY) continue;
         if (job >= P.total_jobs) return false;
         if (job_pixel(P, job, J, split)) break;
     }
@@ -606,6 +673,7 @@ PT_DEV void write_primary(const TraceParams& P, uint32_t job, bool split, uint32
 // mean (path_trace.wgsl:181, :44-49), writes a finished pixel back and claims the next, and regenerates the
 // camera ray of the next sample (random.wgsl:12-14, camera.wgsl:6-19); then starts the closest-hit traversal of
 // `nray`.  `fresh`: the lane has just claimed `job` and has no sample to fold yet.  Returns the lane's next state.
+template <int MODE>
 PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, float* park, float* px_f, uint32_t& job, bool fresh, bool ended,
                           Ray nray, V3 thr, V3 rad, uint32_t rng, uint32_t bounce, bool split = false) {
     const ptx_camera& cam = P.cam;
@@ -621,7 +689,7 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
             float* slot = (float*)&P.staging[(size_t)J.k * P.frame_pixels + J.pix];  // w: the primary hit, written at the first bounce
             slot[0] = r.x; slot[1] = r.y; slot[2] = r.z;
             px_u[6 * 64] += 1u;  // here: paths this lane has finished
-            if (!claim_pixel(P, job, false, px_f, J, true)) return LS_IDLE;
+            if (!claim_pixel<MODE>(P, job, false, px_f, J, true)) return LS_IDLE;
             k_next = J.k;
         } else if (!fresh) {
             PT_SITE(36);
@@ -652,7 +720,7 @@ PT_DEV uint32_t next_path(const DScene& sc, const TraceParams& P, Trav& tv, floa
                 if (P.m2) { P.m2[J.pix * 3] = px_f[3 * 64]; P.m2[J.pix * 3 + 1] = px_f[4 * 64]; P.m2[J.pix * 3 + 2] = px_f[5 * 64]; }
                 P.out_rgba8[J.pix] = tonemap_rgba8(cam, nm);
                 add_paths(P, k_next);
-                if (!claim_pixel(P, job, false, px_f, J)) return LS_IDLE;
+                if (!claim_pixel<MODE>(P, job, false, px_f, J)) return LS_IDLE;
                 k_next = 0u;
             }
         } else {
@@ -894,5 +962,5 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
         }
     }
     if (new_ray && bounce >= cam.max_bounces) ended = true;  // path_trace.wgsl:63
-    return next_path(sc, P, tv, park, px_f, job, false, ended, nray, thr, rad, rng, bounce, split);
+    return next_path<FRAC ? CLAIM_PLAIN : CLAIM_GUIDED>(sc, P, tv, park, px_f, job, false, ended, nray, thr, rad, rng, bounce, split);
 }

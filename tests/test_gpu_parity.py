@@ -496,24 +496,29 @@ def test_both_kernel_families_and_claim_modes_give_identical_frames(pt, name, w,
 
 
 @pytest.mark.parametrize("name,w,h,n,family", [("teapot", 320, 180, 8, 1), ("all", 192, 108, 6, 1), ("fractals", 64, 36, 4, 1),
-                                               ("cornell_box", 320, 180, 4, 0), ("rings", 640, 360, 3, 0)])
+                                               ("cornell_box", 320, 180, 4, 0), ("rings", 640, 360, 3, 0), ("test", 640, 360, 4, 0)])
 def test_reservation_sizes_do_not_change_the_frame(pt, name, w, h, n, family):
     """How many jobs a wave reserves at a time -- fixed sizes from 16 to 1024, a share of the jobs left that shrinks as the
-    launch goes on, or sizes the wave sets by its own pace -- decides only which lane traces which sample: whole-pixel and
-    sample jobs, both kernel families, every setting, same frame."""
+    launch goes on, or sizes the wave sets by its own pace -- and from how many counters (1 to 16, the lockstep kernel's ranged
+    variant) decides only which lane traces which sample: whole-pixel and sample jobs, both kernel families, every setting,
+    same frame."""
     sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
     cam = sc.camera(w, h)
     results = {}
     for split in (1, 0):
         for opts in ({}, dict(claim_tile=16), dict(claim_tile=1024), dict(claim_guided=4), dict(claim_guided=64),
                      dict(claim_guided=8, claim_tile=256), dict(claim_guided=0, claim_tile=128), dict(claim_paced=0, claim_guided=0),
-                     dict(claim_paced=1, claim_cap=0), dict(claim_paced=64, claim_cap=1), dict(claim_paced=4, claim_tile=512)):
+                     dict(claim_paced=1, claim_cap=0), dict(claim_paced=64, claim_cap=1), dict(claim_paced=4, claim_tile=512),
+                     dict(claim_ranges=1), dict(claim_ranges=16), dict(claim_ranges=3, claim_paced=0), dict(claim_ranges=16, claim_tile=1024),
+                     dict(claim_ranges=7, claim_paced=64, claim_cap=0)):
             pt.reset_options()
             pt.set_options(kernel_family=family, split_samples=split, sorted_pool=0, **opts)
             sc.upload_to(pt)
             assert ("sched" in pt.kernel_name()) == (family == 1)
+            want_ranged = family == 0 and opts.get("claim_ranges", 16 if name == "test" else 1) > 1
             pt.resize(w, h)
             pt.trace_n(cam, 0, 1, n)
+            assert ("ranged" in pt.kernel_name()) == want_ranged, (pt.kernel_name(), opts)
             pt.trace_n(cam, n, n + 1, 2)
             st = pt.stats()
             results[(split, tuple(sorted(opts.items())))] = (pt.read_accum(), pt.read_primary_ids(), (st["paths"], st["bounces"], st["shadow_rays"]))
