@@ -97,9 +97,12 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   upload_path    -1 by scene size, 0 record re-layout on the host, 1 on the device
  *   claim_tile      0 per scene and launch; pixel jobs a wave reserves per claim: 1, or a power of two from 16 to 1024
  *   claim_guided   -1 per scene (default), 0 every reservation is claim_tile jobs, k = 4..64: a reservation is 1/(k * waves of the
- *                   launch) of the jobs that were left at the wave's previous one, at least claim_tile
+ *                   launch) of the jobs that were left at the wave's previous one, at least claim_tile (wave-scheduled kernels
+ *                   without fractals)
+ *   claim_ranges    0 per scene (default), else 1..16: job counters the lockstep kernel's reservations are spread over (scenes staged
+ *                   in LDS without fractals; the other kernels use one)
  *   claim_paced    -1 per scene (default), 0 off, m = 1..64: a wave doubles or halves its reservations (64 to 512 jobs) so that they
- *                   come about m * waves * 10 ns apart
+ *                   come about m * waves * 10 ns apart (lockstep kernels)
  *   claim_cap      with paced reservations: -1 = 8 (default), 0 none, k: at most 1/(k * waves) of the jobs left per reservation
  *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)
  *   split_small     -1 every launch (default), else: launches of up to this many samples use them, longer ones fold in the
@@ -169,7 +172,7 @@ int ptx_trace_n(ptx_ctx* ctx, const ptx_camera* cam, uint32_t first_frame, uint3
 /* ptx_trace_n for callers that cannot allocate device memory (code under HIP graph capture, serving loops, harnesses
  * that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same frames, bit for bit; the call
  * itself allocates nothing and creates no events: the launch's scratch (pixel-claim counter, per-wave claim state,
- * traversal-stack entries beyond the LDS part) lives in one array of 56.7 MB (PTX_STATIC_BYTES in the source) that
+ * traversal-stack entries beyond the LDS part) lives in one array of 56.8 MB (PTX_STATIC_BYTES in the source) that
  * every GPU the library runs on holds from load to exit, sized for 4096 waves: what a 256-CU device keeps resident;
  * a larger claiming grid is cut down to that, a launch whose grid follows the frame size (kernel_family 0 on a mesh
  * scene) and runs more waves fails with PTX_ERR_UNSUPPORTED.  Fractal scenes run whole-pixel jobs here (no staging buffer),

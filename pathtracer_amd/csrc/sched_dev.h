@@ -510,8 +510,7 @@ PT_DEV void wave_claim_init(const TraceParams& P, bool ranged) {
 // counter's line).  With claim_tile == 1 a range is exactly what the calling lanes need -- heavy pixels spread over all waves,
 // which serves the fractal scenes (a whole quadrant of silhouette pixels in one wave costs 23 %) and long launches of the
 // Cornell box.  Otherwise a range is claim_tile jobs (64: one 8x8 quadrant, so the lanes of a wave stay on neighbouring
-// pixels, which serves meshes and the Moebius marcher: +4 % / +18 %).  Ranges that shrink with the work left, to even out the
-// end of the launch, measured slower (Cornell box, one sample per launch: 1.5 ms against 1.3).
+// pixels, which serves meshes and the Moebius marcher: +4 % / +18 %), or a size the kernel's claim mode works out (below).
 #define PT_JOB_RETRY 0xFFFFFFFFu  // claim_jobs: the counter ran out under this lane's feet, there may be jobs at another
 // MODE: what the kernel is compiled for (each costs registers: the wave-scheduled kernels have none to spare, and the lockstep
 // kernel's code for the Cornell box is sensitive to all of it) --
