@@ -124,3 +124,33 @@ def test_large_heightfield_bvh_against_oracle_tile(pt):
                          hp.scene_from_fixture(fixture("all"))[1])
     ref = orc.render(orc.OracleScene(sb), cam, n, tile=(200, 200, 128, 64))
     assert same_bits(a[200:264, 200:328], ref["accum"][200:264, 200:328]) == 0
+
+
+@pytest.mark.parametrize("name,w,h", [("test", 1920, 1080), ("planet", 1920, 1080), ("teapot", 3840, 2160)])
+def test_job_handout_at_full_size_does_not_change_the_frame(pt, name, w, h):
+    """At the benchmark's frame sizes the launch-wide job hand-out is what bounds the cheapest scenes, so it has the most
+    variants there: sixteen counters or one, reservations the waves size by their pace, by the launch length or not at all,
+    launches in turn or overlapping.  Every variant must give the frame of whole-pixel jobs from one counter, reserved 64 at a time."""
+    sc = host.Scene.from_fixture(fixture(name)).build(decode_textures=False)
+    cam = sc.camera(w, h)
+
+    def frame(launches, **opts):
+        pt.reset_options()
+        pt.set_options(**opts)
+        sc.upload_to(pt)
+        pt.resize(w, h)
+        done = 0
+        for n in launches:
+            pt.trace_n(cam, done, done + 1, n)
+            done += n
+        st = pt.stats()
+        return pt.read_accum(), pt.read_primary_ids(), (st["paths"], st["bounces"], st["shadow_rays"]), pt.kernel_name()
+
+    ref = frame((4, 1, 2), split_samples=0, claim_tile=64, claim_paced=0, claim_guided=0, claim_ranges=1)
+    default = frame((4, 1, 2))
+    assert ("ranged" in default[3]) == (name != "teapot")
+    for got in (default, frame((1, 1, 1, 1, 1, 1, 1)), frame((4, 1, 2), claim_ranges=1), frame((4, 1, 2), claim_ranges=5, claim_cap=1),
+                frame((7,), sorted_pool=0), frame((4, 1, 2), flights=1, claim_tile=512)):
+        assert same_bits(got[0], ref[0]) == 0 and (got[1] == ref[1]).all() and got[2] == ref[2]
+    pt.reset_options()
+    sc.upload_to(pt)
