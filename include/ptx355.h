@@ -111,8 +111,9 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes
  *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with
  *                  lanes at leaf primitives a state of their own, 2 walks to a leaf, tests wait as their own state
- *   sorted_pool    -1 per scene and launch (default), 0 / 1: launches of more than four samples on the lockstep kernels with
- *                   the scene staged in LDS trace from sorted path pools (see ptx_trace_n)
+ *   sorted_pool    -1 per scene and launch (default: launches of more than four samples trace from sorted path pools when the
+ *                   scene is staged in LDS, or is a shallow mesh with lights; see ptx_trace_n), 0 never, 1 also scenes in
+ *                   global memory that run the lockstep kernels (kernel_family 0)
  *   pool_paths      0 = 4096, else paths per workgroup pool: a power of two from 256 to 16384
  *   grid_per_cu     0 = every resident workgroup, else workgroups per compute unit
  *   flights         launches of sample-granular jobs that may overlap: 0 = per launch (fractal scenes and launches of up to

@@ -1743,13 +1743,17 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Small scenes with a Moebius strip (staged in LDS, wave-scheduled by the per-scene rule): launches of more than four samples
     // run the lockstep kernel over sorted path pools instead (all.yaml 25.1 -> 21.8 ms per 16 samples at 1080p, mebius.yaml
     // 17.3 -> 14.6; lane-owned lockstep 27.5 / 15.8), shorter ones stay wave-scheduled.  Same LDS bytes, same occupancy.
-    const bool sched = c->sched && !(c->opt.family < 0 && c->opt.sorted_pool != 0 && c->sc.lds_scene_bytes > 0u && !frac && n > 4u && !fixed &&
+    // Shallow meshes with lights (unit_logo.yaml: six bounces and five occlusion queries per path) likewise: 72 -> 44 ms per 16
+    // samples at 1080p; without lights (a bounce or two into the sky) the wave-scheduled kernels are up to twice as fast as pools.
+    const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
+    const bool sched = c->sched && !(c->opt.family < 0 && c->opt.sorted_pool != 0 && (c->sc.lds_scene_bytes > 0u || lit_mesh) && !frac && n > 4u && !fixed &&
                                      c->split && !c->dbg && n <= c->split_upto);
-    TraceKernel kernel = sched == c->sched ? trace_kernel_of(c) : ptx_trace_kernel_lds;
+    TraceKernel kernel = sched == c->sched ? trace_kernel_of(c) : (c->sc.lds_scene_bytes > 0u ? ptx_trace_kernel_lds : ptx_trace_kernel);
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
-    const bool claim = sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (c->opt.sorted_pool == 1 && !frac && n > 4u);  // the pools' grid is the resident workgroups too
+    const bool pools_global = c->opt.sorted_pool == 1 || (c->opt.sorted_pool != 0 && lit_mesh && !sched);
+    const bool claim = sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (pools_global && !frac && n > 4u);  // the pools' grid is the resident workgroups too
     uint32_t grid = P.n_blocks;
     if (claim) {
         int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
@@ -1846,7 +1850,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     }
     // Long launches of sample jobs on the lockstep LDS kernels trace from sorted path pools (sorted_body); short ones, whose
     // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !sched && !frac && n > 4u && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : c->opt.sorted_pool == 1);
+    const bool sorted = split && !sched && !frac && n > 4u && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : pools_global);
     if (sorted) {
         // measured on the Cornell box, Gpath-bounce/s at 16 / 128 samples per launch: 1024 paths 11.6 / 12.3, 2048 12.2 / 13.2,
         // 4096 12.5 / 13.6, 8192 12.0 / 13.8, 16384 11.0 / 13.9 (a longer launch amortises a larger pool's first and last rounds)

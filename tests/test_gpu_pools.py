@@ -68,6 +68,12 @@ def test_pools_over_scenes_read_from_global_memory(pt, name):
     got = _render(pt, sc, cam, w, h, [(0, 1, n)], kernel_family=0, sorted_pool=1, split_small=64, pool_paths=1024)
     assert _same(got, want)
     assert got[5] == ("ptx_trace_kernel_sorted" if name != "all" else got[5])  # all.yaml fits LDS: the LDS form
+    # by default: a shallow mesh with lights traces launches of more than four samples from pools, one without stays wave-scheduled
+    dflt = _render(pt, sc, cam, w, h, [(0, 1, n)])
+    assert _same(dflt, want)
+    assert dflt[5] == {"teapot": "ptx_sched_kernel_samples", "unit_logo": "ptx_trace_kernel_sorted", "all": "ptx_trace_kernel_lds_sorted"}[name]
+    short = _render(pt, sc, cam, w, h, [(0, 1, 3), (3, 4, 3)])
+    assert _same(short, want) and "sched" in short[5]
 
 
 def test_pools_equal_lane_owned_paths_with_tiles_partitions_and_continuation(pt):
