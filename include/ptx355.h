@@ -114,7 +114,9 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   sorted_pool    -1 per scene and launch (default: launches of more than four samples trace from sorted path pools when the
  *                   scene is staged in LDS, or is a shallow mesh with lights; see ptx_trace_n), 0 never, 1 also scenes in
  *                   global memory that run the lockstep kernels (kernel_family 0)
- *   pool_paths      0 = 4096, else paths per workgroup pool: a power of two from 256 to 16384
+ *   pool_over      -1 per scene (default: 4; shallow meshes with lights 0), else launches of more samples than this may trace from pools
+ *   pool_paths      0 = by launch length (2048 / 4096 / 8192 for up to 4 / under 64 / more samples), else paths per workgroup
+ *                   pool: a power of two from 256 to 16384
  *   grid_per_cu     0 = every resident workgroup, else workgroups per compute unit
  *   flights         launches of sample-granular jobs that may overlap: 0 = per launch (fractal scenes and launches of up to
  *                   four samples: six, or as many as fit 8 GiB of staging buffers, at least two; longer launches of other

@@ -1022,6 +1022,7 @@ struct ptx_ctx {
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
         int sorted_pool = -1;     // -1 per scene and launch, 0 / 1: lockstep LDS kernel over sorted path pools (sample jobs, long launches)
+        int pool_over = -1;       // -1 per scene (4; lit meshes 0): launches of more samples than this may trace from pools
         uint32_t pool_paths = 0;  // 0 = 4096, else paths per workgroup pool (a power of two from 256 to 16384)
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
         int64_t split_upto = -1;  // split_small: -1 per scene, else launches of up to this many samples run sample jobs (fractal scenes on the scheduled kernels always do)
@@ -1367,6 +1368,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
     else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
     else if (k == "sorted_pool") { if ((ok = in(-1, 1))) o.sorted_pool = (int)value; }
+    else if (k == "pool_over") { if ((ok = in(-1, 0x7FFFFFFF))) o.pool_over = (int)value; }
     else if (k == "pool_paths") { if ((ok = value == 0 || (value >= 256 && value <= 16384 && (value & (value - 1)) == 0))) o.pool_paths = (uint32_t)value; }
     else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
     else if (k == "flights") { if ((ok = in(0, PTX_FLIGHTS))) o.flights = (uint32_t)value; }
@@ -1746,14 +1748,19 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Shallow meshes with lights (unit_logo.yaml: six bounces and five occlusion queries per path) likewise: 72 -> 44 ms per 16
     // samples at 1080p; without lights (a bounce or two into the sky) the wave-scheduled kernels are up to twice as fast as pools.
     const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
-    const bool sched = c->sched && !(c->opt.family < 0 && c->opt.sorted_pool != 0 && (c->sc.lds_scene_bytes > 0u || lit_mesh) && !frac && n > 4u && !fixed &&
+    // Launches of more samples than this may trace from pools.  Pools do not overlap with the next launch (one set per context),
+    // lane-owned launches of up to four samples do: back to back the Cornell box loses 10-50 % at one sample per launch from
+    // pools, gains 8 % at four, rings.yaml loses 23 % at four (in turn pools win from two samples up).  A lit mesh's paths
+    // are long enough for pools to win at every length (unit_logo.yaml, one / four samples per launch: 430 -> 610 / 471 -> 750 Mpaths/s).
+    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : (lit_mesh ? 0u : 4u);
+    const bool sched = c->sched && !(c->opt.family < 0 && c->opt.sorted_pool != 0 && (c->sc.lds_scene_bytes > 0u || lit_mesh) && !frac && n > pool_over && !fixed &&
                                      c->split && !c->dbg && n <= c->split_upto);
     TraceKernel kernel = sched == c->sched ? trace_kernel_of(c) : (c->sc.lds_scene_bytes > 0u ? ptx_trace_kernel_lds : ptx_trace_kernel);
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
     const bool pools_global = c->opt.sorted_pool == 1 || (c->opt.sorted_pool != 0 && lit_mesh && !sched);
-    const bool claim = sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (pools_global && !frac && n > 4u);  // the pools' grid is the resident workgroups too
+    const bool claim = sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (pools_global && !frac && n > pool_over);  // the pools' grid is the resident workgroups too
     uint32_t grid = P.n_blocks;
     if (claim) {
         int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
@@ -1850,11 +1857,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     }
     // Long launches of sample jobs on the lockstep LDS kernels trace from sorted path pools (sorted_body); short ones, whose
     // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !sched && !frac && n > 4u && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : pools_global);
+    const bool sorted = split && !sched && !frac && n > pool_over && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : pools_global);
     if (sorted) {
         // measured on the Cornell box, Gpath-bounce/s at 16 / 128 samples per launch: 1024 paths 11.6 / 12.3, 2048 12.2 / 13.2,
         // 4096 12.5 / 13.6, 8192 12.0 / 13.8, 16384 11.0 / 13.9 (a longer launch amortises a larger pool's first and last rounds)
-        const uint32_t m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : 4096u);
+        const uint32_t m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : 2048u));
         if ((size_t)grid > c->pool_wgs || m > c->pool_m) {  // the buffers only grow: a smaller pool uses a part of each workgroup's share
             const size_t wgs = (size_t)grid > c->pool_wgs ? (size_t)grid : c->pool_wgs;
             const uint32_t cap = m > c->pool_m ? m : c->pool_m;
