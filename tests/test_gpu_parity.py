@@ -273,8 +273,9 @@ def test_frame_loop_follows_reference_ordering(pt):
     assert loop.acc.sample_count == 4 and loop.acc.frame_index == 7
 
 
-def test_tiles_and_interleaved_partitions_reassemble_the_frame(pt):
-    sb = hp.prepare_fixture(fixture("cornell_box"))
+@pytest.mark.parametrize("name", ["cornell_box", "test", "unit_logo"])  # one job counter; sixteen; path pools over a mesh
+def test_tiles_and_interleaved_partitions_reassemble_the_frame(pt, name):
+    sb = hp.prepare_fixture(fixture(name))
     w, h, n = 100, 70, 3
     cam = hp.camera_to_gpu(sb.camera, w, h)
     _upload(pt, sb)
