@@ -47,7 +47,7 @@
 // from module load to process exit; every call on a device shares it.
 #define PTX_FLIGHTS 8  // launches of sample-granular jobs that may be in flight at once (their staging buffers: 8 GiB together at most)
 #define PTX_FLIGHTS_DEFAULT 6u
-#define PTX_CLAIM_RANGES 16  // job counters of a launch at most
+#define PTX_CLAIM_RANGES 16  // job counters of a launch at most (their run-out bits share one 32-bit word)
 #define PTX_STATIC_MAX_WAVES 4096u
 #define PTX_STATIC_WAVES_OFFSET 256u
 #define PTX_STATIC_SPILL_OFFSET (PTX_STATIC_WAVES_OFFSET + PTX_STATIC_MAX_WAVES * 32u)  // sizeof(WaveState)
@@ -1813,10 +1813,10 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
                                    : (c->opt.claim_ranges ? c->opt.claim_ranges : (c->sc.nfig <= 8u ? (uint32_t)PTX_CLAIM_RANGES : 1u));
     if (claim) {
         if (!fixed && !c->flight_counters) {
-            HIP_TRY(c, hipMalloc((void**)&c->flight_counters, (PTX_FLIGHTS + 1) * PTX_CLAIM_RANGES * 256));
-            HIP_TRY(c, hipMemset(c->flight_counters, 0, (PTX_FLIGHTS + 1) * PTX_CLAIM_RANGES * 256));
+            HIP_TRY(c, hipMalloc((void**)&c->flight_counters, (PTX_FLIGHTS + 1) * (PTX_CLAIM_RANGES + 1) * 256));
+            HIP_TRY(c, hipMemset(c->flight_counters, 0, (PTX_FLIGHTS + 1) * (PTX_CLAIM_RANGES + 1) * 256));
         }
-        P.job_counter = fixed ? (uint32_t*)c->static_scratch : c->flight_counters + PTX_FLIGHTS * PTX_CLAIM_RANGES * 64;
+        P.job_counter = fixed ? (uint32_t*)c->static_scratch : c->flight_counters + PTX_FLIGHTS * (PTX_CLAIM_RANGES + 1) * 64;
         P.total_jobs = P.n_blocks * 256u;
         P.claim_tile = c->claim_tile;
         // Lockstep kernels: short launches are bound by the rate of the claims (one device atomic per finished pixel and wave),
@@ -1922,7 +1922,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             P.split_n = 0u; P.total_jobs = P.n_blocks * 256u;
             if (claim) {
                 set_ranges(P, ranges, grid * 256u);
-                if (zero_based) HIP_TRY(c, hipMemsetAsync(P.job_counter, 0, P.claim_ranges * 256u, c->stream));
+                if (zero_based) HIP_TRY(c, hipMemsetAsync(P.job_counter, 0, (P.claim_ranges + 1u) * 256u, c->stream));  // the counters and the word that says which have run out
                 else HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, c->stream));
             }
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, c->stream, P);
@@ -1976,10 +1976,10 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         if (f.used) HIP_TRY(c, hipStreamWaitEvent(f.stream, f.folded, 0));
         P.staging = f.staging;
         P.wave_state = f.wave_state;
-        P.job_counter = c->flight_counters + slot * (PTX_CLAIM_RANGES * 64u);
+        P.job_counter = c->flight_counters + slot * ((PTX_CLAIM_RANGES + 1) * 64u);
         // the lane-owned kernels start with jobs 0 .. grid * 256 - 1 in their lanes; the pools reserve every job they trace
         set_ranges(P, sorted ? 1u : ranges, sorted ? 0u : grid * 256u);
-        if (zero_based || sorted) HIP_TRY(c, hipMemsetAsync(P.job_counter, 0, P.claim_ranges * 256u, f.stream));
+        if (zero_based || sorted) HIP_TRY(c, hipMemsetAsync(P.job_counter, 0, (P.claim_ranges + 1u) * 256u, f.stream));
         else HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)P.job_counter, (int)(grid * 256u), 1, f.stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PTX_BLOCK), lds_all, f.stream, P);
         HIP_TRY(c, hipGetLastError());

@@ -484,7 +484,7 @@ PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J, bool spli
 struct WaveState {
     uint32_t next, end, paths;  // the jobs it has reserved and not handed out; paths finished
     uint32_t pace;              // paced reservations: when the previous one was made and how large it was (claim_jobs)
-    uint32_t range;             // the counter it reserves from | how many counters it has found exhausted << 8 (all of them: no jobs left)
+    uint32_t range;             // the counter it reserves from
     uint32_t pad[3];
 };
 static_assert(sizeof(WaveState) == 32, "WaveState");
@@ -583,23 +583,29 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
         }
         return rank < avail ? next + rank : base + (rank - avail);
     }
-    // which counter, and how many the wave has found exhausted: one word
-    const uint32_t rt = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    uint32_t r = rt & 0xFFu, tried = rt >> 8;
-    if (P.claim_period) {
-        // the jobs left, estimated from where this wave's counter stood after its previous reservation (`end`): the other
-        // counters stand about as far into their ranges
-        uint32_t r_end = P.job_first + (r + 1u) * P.range_len;
-        r_end = r_end < P.total_jobs ? r_end : P.total_jobs;
-        uint32_t left = (end == 0u ? P.range_len : (end < r_end ? r_end - end : 0u)) * P.claim_ranges;
-        left = left < P.total_jobs ? left : P.total_jobs;
-        chunk = paced_size(P, ws, chunk, left, lane == leader);
-    }
-    chunk = want > chunk ? want : chunk;
-    // One device atomic on the wave's current counter.  A counter that has run out sends the wave on to the next (the lanes
-    // without a job ask again: PT_JOB_RETRY); a wave that has found every counter exhausted asks no more.
+    // Which counter the wave reserves from: its own word.  Which counters have run out: a word all waves share, behind the
+    // counters -- read here (a load, not an atomic), so that at the end of the launch a wave sees every bit set and asks no more
+    // (finding out counter by counter cost every wave sixteen failed atomics at the end of every launch).
+    uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ws->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    uint32_t* out_mask = P.job_counter + P.claim_ranges * 64u;
+    const uint32_t all = (1u << P.claim_ranges) - 1u;
+    const uint32_t open = ~(uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(out_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & all;
     uint32_t base = P.total_jobs, got = 0u;
-    if (tried < P.claim_ranges) {
+    if (open != 0u) {
+        // the first counter at or after r that has not run out, cyclically
+        const uint32_t ahead = open >> r << r;
+        r = (uint32_t)__builtin_ctz(ahead ? ahead : open);
+        if (P.claim_period) {
+            // the jobs left, estimated from where this wave's counter stood after its previous reservation (`end`): the other
+            // counters stand about as far into their ranges
+            uint32_t r_end = P.job_first + (r + 1u) * P.range_len;
+            r_end = r_end < P.total_jobs ? r_end : P.total_jobs;
+            uint32_t left = (end == 0u || end > r_end || end + P.range_len < r_end ? P.range_len : r_end - end) * P.claim_ranges;
+            left = left < P.total_jobs ? left : P.total_jobs;
+            chunk = paced_size(P, ws, chunk, left, lane == leader);
+        }
+        chunk = want > chunk ? want : chunk;
+        // one device atomic on that counter; if it has just run out, the wave says so and its lanes ask again (PT_JOB_RETRY)
         uint32_t local = 0u;
         if (lane == leader) local = atomicAdd(P.job_counter + r * 64u, chunk);
         local = (uint32_t)__builtin_amdgcn_readlane((int)local, (int)leader);
@@ -609,20 +615,21 @@ PT_DEV uint32_t claim_jobs(const TraceParams& P) {
         if (local < P.range_len && start + local < r_end) {
             base = start + local;
             got = r_end - base < chunk ? r_end - base : chunk;
-        } else {
-            r = r + 1u == P.claim_ranges ? 0u : r + 1u;
-            tried += 1u;
+        } else if (lane == leader) {
+            atomicOr(out_mask, 1u << r);
         }
         if (lane == leader) {
             __hip_atomic_store(&ws->next, base + (want < got ? want : got), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ws->end, base + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws->range, r | tried << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws->range, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if (avail != 0u && lane == leader) {
+        __hip_atomic_store(&ws->next, end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the last of its reserve goes to the first lanes below
     }
     if (rank < avail) return next + rank;
     const uint32_t k = rank - avail;
     if (k < got) return base + k;
-    return tried < P.claim_ranges ? PT_JOB_RETRY : P.total_jobs;
+    return open != 0u ? PT_JOB_RETRY : P.total_jobs;
 }
 // Claims jobs until one lies inside the tile; loads that pixel's accumulator into the lane's LDS slots.
 template <int MODE>

@@ -528,3 +528,34 @@ def test_reservation_sizes_do_not_change_the_frame(pt, name, w, h, n, family):
     for key, r in results.items():
         assert same_bits(r[0], ref[0]) == 0 and (r[1] == ref[1]).all() and r[2] == ref[2], key
     sc.upload_to(pt)
+
+
+def test_every_job_is_traced_once_when_the_counters_run_out(pt):
+    """The end of a launch from sixteen counters: waves holding part of a reservation while every counter has run out, lanes
+    that ask again after their counter ran out under them.  Timing decides which wave meets which case, so: many launches of
+    many sizes (jobs from a few dozen to twenty per lane), whole-pixel jobs (a job traced twice would fold its samples twice)
+    and sample jobs, each checked for its path count and against the frame from one counter."""
+    sc = host.Scene.from_fixture(fixture("planet")).build(decode_textures=False)
+    sizes = [(16, 16), (100, 70), (255, 130), (640, 360), (1001, 563), (1920, 1080)]
+    for w, h in sizes:
+        cam = sc.camera(w, h)
+        pt.reset_options()
+        pt.set_options(claim_ranges=1, claim_paced=0, split_samples=0)
+        sc.upload_to(pt)
+        pt.resize(w, h)
+        pt.trace_n(cam, 0, 1, 3)
+        ref = pt.read_accum()
+        for split in (0, 1):
+            for ranges, rep in ((16, 6), (5, 2), (2, 2)):
+                pt.reset_options()
+                pt.set_options(claim_ranges=ranges, split_samples=split)
+                sc.upload_to(pt)
+                pt.resize(w, h)
+                for _ in range(rep):
+                    pt.clear()
+                    pt.trace_n(cam, 0, 1, 3)
+                    assert "ranged" in pt.kernel_name()
+                    assert pt.stats()["paths"] == w * h * 3, (w, h, split, ranges)
+                    assert same_bits(pt.read_accum(), ref) == 0, (w, h, split, ranges)
+    pt.reset_options()
+    sc.upload_to(pt)
