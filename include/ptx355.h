@@ -99,9 +99,9 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   claim_guided   -1 per scene (default), 0 every reservation is claim_tile jobs, k = 4..64: a reservation is 1/(k * waves of the
  *                   launch) of the jobs that were left at the wave's previous one, at least claim_tile (wave-scheduled kernels
  *                   without fractals)
- *   claim_ranges    0 per scene (default), else 1..16: job counters the lockstep kernel's reservations are spread over (scenes staged
- *                   in LDS without fractals; the other kernels use one)
- *   claim_paced    -1 per scene (default), 0 off, m = 1..64: a wave doubles or halves its reservations (64 to 512 jobs) so that they
+ *   claim_ranges    0 per scene (default: sixteen for scenes staged in LDS that have no lights, else one), else 1..16: job counters
+ *                   the lockstep kernel's reservations are spread over (scenes staged in LDS without fractals; the other kernels use one)
+ *   claim_paced    -1 per scene (default), 0 off, m = 1..64: a wave doubles or halves its reservations (claim_tile to 512 jobs) so that they
  *                   come about m * waves * 10 ns apart (lockstep kernels)
  *   claim_cap      with paced reservations: -1 = 8 (default), 0 none, k: at most 1/(k * waves) of the jobs left per reservation
  *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)

@@ -1807,10 +1807,12 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // memory wants (every wave walks the same part of it).  Scenes whose paths cost little want reservations served faster than one
     // address can (88 M a second): sixteen counters, each handing out a sixteenth of the jobs, a wave moving on when its counter runs out.
     // Only the lockstep kernel has the registers for it, in a variant of its own (CLAIM_RANGED, sched_dev.h: its counters count
-    // from zero, the others' one counter from the first unassigned job), for scenes of a handful of figures: the Cornell box
-    // (13 figures) and rings.yaml (19) lose 3 % with sixteen counters, test.yaml (3) doubles, aelita.yaml (5) gains a fifth.
+    // from zero, the others' one counter from the first unassigned job), and only scenes without lights run it: their paths end
+    // at the sky after a bounce or two, and the hand-out is what bounds them (test.yaml, planet.yaml: 1.5 to 2.5 times the rate at
+    // every frame size, in turn and back to back).  Scenes with lights (three bounces per path and more) gain up to a quarter at
+    // 1080p in turn and lose 5-12 % at 4K and back to back: the variant's code is a few per cent slower than the plain kernel's.
     const uint32_t ranges_wanted = sched || frac || fixed || c->sc.lds_scene_bytes == 0u ? 1u
-                                   : (c->opt.claim_ranges ? c->opt.claim_ranges : (c->sc.nfig <= 8u ? (uint32_t)PTX_CLAIM_RANGES : 1u));
+                                   : (c->opt.claim_ranges ? c->opt.claim_ranges : (c->sc.nlight == 0u ? (uint32_t)PTX_CLAIM_RANGES : 1u));
     if (claim) {
         if (!fixed && !c->flight_counters) {
             HIP_TRY(c, hipMalloc((void**)&c->flight_counters, (PTX_FLIGHTS + 1) * (PTX_CLAIM_RANGES + 1) * 256));

@@ -517,12 +517,12 @@ PT_DEV void wave_claim_init(const TraceParams& P, bool ranged) {
 // CLAIM_PLAIN   one counter, which starts at the first unassigned job, reservations of claim_tile jobs (the fractal kernels);
 // CLAIM_GUIDED  the same with sizes by the jobs left (claim_shift; the other wave-scheduled kernels);
 // CLAIM_PACED   the same with sizes by the wave's pace (claim_period; the lockstep kernels);
-// CLAIM_RANGED  several counters, which start at zero, sizes by the wave's pace (the lockstep kernel for scenes of a few figures).
+// CLAIM_RANGED  several counters, which start at zero, sizes by the wave's pace (the lockstep kernel for scenes without lights).
 // The host sets the parameters to match (launch_trace).
 enum : int { CLAIM_PLAIN = 0, CLAIM_GUIDED = 1, CLAIM_PACED = 2, CLAIM_RANGED = 3 };
 // The wave's own pace sets the size of its reservations: its record keeps when the previous one was made (24 bits of the
 // 100 MHz clock, which wrap after 168 ms) and how large it was (in 64 jobs, the top byte).  Used up in under 2/3 of claim_period:
-// the next is twice as large; it lasted over 3/2: half; 64 to 512 jobs, and no more than the jobs left >> claim_cap_shift.
+// the next is twice as large; it lasted over 3/2: half; claim_tile to 512 jobs, and no more than the jobs left >> claim_cap_shift.
 // Scalar integer work only (shifts and compares): the kernels have no vector register to spare here.
 PT_DEV uint32_t paced_size(const TraceParams& P, WaveState* ws, uint32_t first_size, uint32_t left, bool leader) {
     const uint32_t now = (uint32_t)wall_clock64() & 0xFFFFFFu;
@@ -540,7 +540,8 @@ PT_DEV uint32_t paced_size(const TraceParams& P, WaveState* ws, uint32_t first_s
         const uint32_t cap = left >> P.claim_cap_shift;
         units = units > cap ? cap : units;
     }
-    units = units < 1u ? 1u : units;
+    const uint32_t least = first_size >> 6;  // never below the fixed size of this launch (128 jobs for frames of 4 M pixels and more)
+    units = units < least ? least : units;
     if (leader) __hip_atomic_store(&ws->pace, units << 24 | now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return units << 6;
 }
