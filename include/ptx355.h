@@ -107,6 +107,8 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)
  *   split_small     -1 every launch (default), else: launches of up to this many samples use them, longer ones fold in the
  *                   lane (fractal scenes on the wave-scheduled kernels always use them)
+ *   idle_whole      1 (default) / 0: a one-sample launch that finds the previous launch finished (a host that reads every frame
+ *                   back) runs whole-pixel jobs, as it has no neighbour to overlap with (lockstep kernels, meshes without lights)
  *   split_chunk     0 = bounded by the staging buffer, else samples per chunk
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes
  *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with

@@ -1022,6 +1022,7 @@ struct ptx_ctx {
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
         int sorted_pool = -1;     // -1 per scene and launch, 0 / 1: lockstep LDS kernel over sorted path pools (sample jobs, long launches)
+        int idle_whole = 1;       // 1: a one-sample launch that finds the GPU idle runs whole-pixel jobs (no staging, no fold kernel); 0 never
         int pool_over = -1;       // -1 per scene (4; lit meshes 0): launches of more samples than this may trace from pools
         uint32_t pool_paths = 0;  // 0 = 4096, else paths per workgroup pool (a power of two from 256 to 16384)
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
@@ -1069,6 +1070,8 @@ struct ptx_ctx {
     size_t xchg_floats = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::chrono::steady_clock::time_point last_launch{};  // when the latest trace launch was enqueued (host clock)
+    bool found_idle = false;                               // ... and whether it found the one before it finished
     std::vector<hipEvent_t> free_events;
     double acc_ms = 0.0;
     uint32_t acc_launches = 0;
@@ -1368,6 +1371,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
     else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
     else if (k == "sorted_pool") { if ((ok = in(-1, 1))) o.sorted_pool = (int)value; }
+    else if (k == "idle_whole") { if ((ok = in(0, 1))) o.idle_whole = (int)value; }
     else if (k == "pool_over") { if ((ok = in(-1, 0x7FFFFFFF))) o.pool_over = (int)value; }
     else if (k == "pool_paths") { if ((ok = value == 0 || (value >= 256 && value <= 16384 && (value & (value - 1)) == 0))) o.pool_paths = (uint32_t)value; }
     else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
@@ -1848,7 +1852,27 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     // Which scenes and launch sizes use this form is measured per scene class (configure()): all but long launches of shallow
     // meshes without marched figures.  Staging costs 16 bytes per sample, written once and read once: 4.2 GB per 128-sample
     // launch of a 1080p frame, two such buffers in flight.
-    const bool split = !fixed && claim && c->split && !c->dbg && n <= c->split_upto;
+    // One sample per launch with the GPU idle -- a host that reads every frame back before it asks for the next, as the
+    // reference's own frame loop presents every frame -- has no neighbour to overlap with: there the pixel folds its sample in
+    // the lane and no fold kernel follows (1080p, in turn: Cornell box 1.42 -> 1.24 ms, cube.yaml 0.67 -> 0.59, test.yaml
+    // 0.43 -> 0.31, teapot 0.85 -> 0.76; deep trees and the Moebius scenes lose 1-4 % and keep sample jobs).  A launch that
+    // finds the previous one still running is in a back-to-back sequence and overlaps with it as sample jobs.
+    // (The event is asked only when the previous launch was enqueued more than 0.2 ms ago: a host that enqueues launch after
+    // launch never asks -- the query cost the Cornell box 1-4 % back to back.)
+    bool alone = false;
+    const auto now = std::chrono::steady_clock::now();
+    if (n == 1u && !fixed && !frac && c->opt.idle_whole != 0 && (!c->sched || (c->plain_mesh && !lit_mesh)) &&
+        std::chrono::duration<double, std::micro>(now - c->last_launch).count() > 200.0) {
+        // twice in a row: the first launch of a back-to-back burst finds the GPU idle too, and a whole-pixel launch at its head
+        // would keep the second from starting beside it
+        const bool idle = c->pending.empty() || hipEventQuery(c->pending.back().second) == hipSuccess;
+        alone = idle && c->found_idle;
+        c->found_idle = idle;
+    } else {
+        c->found_idle = false;
+    }
+    c->last_launch = now;
+    const bool split = !fixed && claim && c->split && !c->dbg && n <= c->split_upto && !alone;
     if (split && sched && !frac) {
         kernel = c->sc.lds_scene_bytes > 0u ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
         // the slots of the running mean, which sample jobs do not keep, hold two more stack entries (same LDS bytes: sched_body)

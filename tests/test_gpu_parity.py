@@ -559,3 +559,31 @@ def test_every_job_is_traced_once_when_the_counters_run_out(pt):
                     assert same_bits(pt.read_accum(), ref) == 0, (w, h, split, ranges)
     pt.reset_options()
     sc.upload_to(pt)
+
+
+def test_a_host_that_waits_for_every_frame_gets_whole_pixel_launches_and_the_same_frame(pt):
+    """One sample per launch: back to back the launches overlap as sample jobs; a host that waits for each frame before it asks for
+    the next finds the GPU idle, and from the second such launch on the library folds the sample in the lane (no staging, no
+    fold kernel).  Same frame either way, and with the choice switched off."""
+    import time
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build(decode_textures=False)
+    w, h, n = 160, 90, 6
+    cam = sc.camera(w, h)
+    frames = {}
+    for mode in ("burst", "waiting", "waiting, choice off"):
+        pt.reset_options()
+        if mode.endswith("off"):
+            pt.set_options(idle_whole=0)
+        sc.upload_to(pt)
+        pt.resize(w, h)
+        for k in range(n):
+            pt.trace_n(cam, k, k + 1, 1)
+            if mode != "burst":
+                pt.sync()
+                time.sleep(0.002)
+        frames[mode] = (pt.read_accum(), pt.read_primary_ids(), pt.stats()["paths"])
+    ref = frames["burst"]
+    for mode, f in frames.items():
+        assert same_bits(f[0], ref[0]) == 0 and (f[1] == ref[1]).all() and f[2] == ref[2] == w * h * n, mode
+    pt.reset_options()
+    sc.upload_to(pt)
