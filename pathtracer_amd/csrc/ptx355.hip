@@ -1865,7 +1865,11 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         std::chrono::duration<double, std::micro>(now - c->last_launch).count() > 200.0) {
         // twice in a row: the first launch of a back-to-back burst finds the GPU idle too, and a whole-pixel launch at its head
         // would keep the second from starting beside it
-        const bool idle = c->pending.empty() || hipEventQuery(c->pending.back().second) == hipSuccess;
+        bool idle = c->pending.empty();
+        if (!idle) {
+            idle = hipEventQuery(c->pending.back().second) == hipSuccess;
+            (void)hipGetLastError();  // "not ready" is an answer, not an error: it must not be what the launch below reports
+        }
         alone = idle && c->found_idle;
         c->found_idle = idle;
     } else {

@@ -570,15 +570,27 @@ def test_a_host_that_waits_for_every_frame_gets_whole_pixel_launches_and_the_sam
     w, h, n = 160, 90, 6
     cam = sc.camera(w, h)
     frames = {}
-    for mode in ("burst", "waiting", "waiting, choice off"):
+    for mode in ("burst", "waiting", "waiting, choice off", "slow host, busy GPU"):
         pt.reset_options()
         if mode.endswith("off"):
             pt.set_options(idle_whole=0)
         sc.upload_to(pt)
         pt.resize(w, h)
+        if mode.startswith("slow"):  # a long launch first: the next ones come a millisecond apart and find it still running
+            pt.trace_n(cam, 0, 1, 1)
+            pt.sync()
+            big = sc.camera(1920, 1080)
+            pt.resize(1920, 1080)
+            pt.trace_n(big, 0, 1, 64)
+            for k in range(3):
+                time.sleep(0.001)
+                pt.trace_n(big, 64 + k, 65 + k, 1)
+            pt.sync()
+            assert pt.stats()["paths"] == 1920 * 1080 * 67
+            pt.resize(w, h)
         for k in range(n):
             pt.trace_n(cam, k, k + 1, 1)
-            if mode != "burst":
+            if mode.startswith("waiting"):
                 pt.sync()
                 time.sleep(0.002)
         frames[mode] = (pt.read_accum(), pt.read_primary_ids(), pt.stats()["paths"])
