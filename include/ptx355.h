@@ -249,14 +249,21 @@ int ptx_merge_moments(ptx_ctx* ctx, uint32_t first_pixel, uint32_t n_pixels, uin
  *     0, 1, 2, ... (the arithmetic of ptx_merge_moments: deterministic, equal to the sequential mean to rounding,
  *     <= 1e-5 relative), and the merged slices go back to every rank; then the rgba8 image of the whole frame is
  *     re-derived.  On return (asynchronous on the context's stream) every rank holds the merged mean, M2 and image.
- *   ptx_assemble_tiles: the epilogue of a tile partition (ptx_set_partition): one SUM all-reduce of the disjoint
- *     accumulation buffers (exact: untouched pixels are zero), then the rgba8 image of the whole frame. */
+ *     A rank with counts[r] == 0 contributes nothing, whatever its buffers hold.
+ *   ptx_assemble_tiles: the epilogue of a tile partition.  When the context's partition (ptx_set_partition) is the
+ *     communicator's rank and size, every rank sends the 16x16 blocks it traced to every peer and receives theirs (no
+ *     arithmetic: exact); for any other disjoint split one SUM all-reduce of the accumulation buffers (exact: untouched
+ *     pixels are zero).  Then the rgba8 image of the whole frame. */
 int ptx_comm_unique_id(void* id128);
 int ptx_comm_init(ptx_ctx* ctx, const void* id128, uint32_t rank, uint32_t world);
 int ptx_comm_adopt(ptx_ctx* ctx, void* nccl_comm);
 int ptx_comm_free(ptx_ctx* ctx);
 int ptx_merge_sample_split(ptx_ctx* ctx, const uint32_t* counts, const ptx_camera* cam);
 int ptx_assemble_tiles(ptx_ctx* ctx, const ptx_camera* cam);
+/* The slice of the frame's n_pixels that `rank` of `world` merges in ptx_merge_sample_split: contiguous pixel ranges whose
+ * sizes differ by at most one (the first n_pixels % world are the longer ones; empty when there are more ranks than
+ * pixels).  A pure function (no context, no GPU): hosts and tests that stage the exchange themselves use the same plan. */
+void ptx_slice_of(uint64_t n_pixels, uint32_t world, uint32_t rank, uint64_t* first, uint64_t* count);
 
 /* Re-derives the rgba8 output of pixels [first_pixel, first_pixel + n_pixels) from the accumulation buffer
  * (apply_tonemap + rgba8unorm store, tonemap.wgsl:27-42, path_trace.wgsl:52-53): for accumulation data
@@ -276,6 +283,11 @@ int ptx_read_stats(ptx_ctx* ctx, ptx_stats* out);
  * read from global memory; with or without the fractal marchers); "" before ptx_upload_scene.  For
  * matching profiler output. */
 const char* ptx_trace_kernel_name(const ptx_ctx* ctx);
+/* What the launch policy chose for the latest ptx_trace* call (no reference counterpart; for profiles, bench lines and the
+ * policy tests): "<kernel> jobs=pixels|samples|pools claim_tile=.. counters=.. guided=.. paced=.. pool=.. flights=.. chunk=..
+ * lds_stack=..; grid=..".  The part before ';' depends on the scene, the options and the launch length only, not on the
+ * device's size or on host timing.  "" before the first launch on the uploaded scene. */
+const char* ptx_last_launch_info(const ptx_ctx* ctx);
 
 /* Sum of the trace kernels' durations (HIP events on the context's stream) and their count since the
  * last call; synchronises. */

@@ -49,9 +49,11 @@ SYMBOLS = [
     ("ptx_comm_free", C.c_int, [_P]),
     ("ptx_merge_sample_split", C.c_int, [_P, _P, _P]),
     ("ptx_assemble_tiles", C.c_int, [_P, _P]),
+    ("ptx_slice_of", None, [C.c_uint64, _U, _U, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("ptx_post_process", C.c_int, [_P, _P]),
     ("ptx_read_stats", C.c_int, [_P, C.POINTER(PtxStats)]),
     ("ptx_trace_kernel_name", C.c_char_p, [_P]),
+    ("ptx_last_launch_info", C.c_char_p, [_P]),
     ("ptx_kernel_time", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U)]),
     ("ptx_kernel_times", C.c_int, [_P, _P, _U, C.POINTER(_U)]),
     ("ptx_kat_math", C.c_int, [_P, C.c_int, _U, _P, _P, _P]),
@@ -71,10 +73,12 @@ def load() -> C.CDLL:
         # PyTorch wheels bundle their own HIP runtime.  When a process uses both (multi-GPU runs use
         # torch.distributed for RCCL), torch has to be loaded first so that both resolve to one runtime;
         # loaded the other way round torch later reports "No HIP GPUs are available".
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+        # (PTX355_NO_TORCH=1: a process that must not load torch's bundled libraries, e.g. one that brings its own RCCL.)
+        if os.environ.get("PTX355_NO_TORCH", "") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

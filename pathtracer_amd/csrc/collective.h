@@ -49,7 +49,11 @@ inline Api* api() {
     const char* fresh[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : fresh)
         if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!a.handle) { a.error = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return nullptr; }
+    if (!a.handle) {
+        const char* why = dlerror();  // one call: it returns the message and clears it
+        a.error = std::string("RCCL not found: ") + (why ? why : "dlopen failed");
+        return nullptr;
+    }
     bool ok = true;
     auto sym = [&](const char* name) { void* p = dlsym(a.handle, name); if (!p) { ok = false; a.error = std::string("RCCL symbol missing: ") + name; } return p; };
     a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");

@@ -405,8 +405,17 @@ PT_DEV void sorted_body(const TraceParams& P) {
         if (threadIdx.x == RG_BINS) { cv[1] = 0u; cv[2] = 0u; }
         wg_sync();
         uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[0]);
+        const uint32_t no_jobs_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[4]);
         if (count > M) count = M;
-        if (count == 0u) break;  // the same for every wave of the workgroup
+        if (count == 0u) {  // the same for every wave of the workgroup
+            // An empty pool ends the workgroup only when the launch has no jobs left to reserve: a reservation may lie wholly
+            // outside the tile (the right and bottom quadrants of edge blocks: 64 * n consecutive jobs), and then the next
+            // top-up has to go on reserving.  The barrier keeps thread 0 from writing the next round's flags while the other
+            // waves still read this round's.
+            if (no_jobs_left != 0u || P.n == 0u) break;
+            wg_sync();
+            continue;
+        }
         // ---- sort: the order the current buffer is traced in
         for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
         wg_sync();
@@ -843,6 +852,27 @@ extern "C" __global__ void ptx_tonemap_kernel(const float4* accum, uint32_t* out
     out_rgba8[(size_t)first + i] = tonemap_rgba8(cam, v3(a.x, a.y, a.z));
 }
 
+// Tile partition (ptx_set_partition): the 16x16-pixel blocks of the tile whose row-major index is congruent to `rank` modulo
+// `world` belong to that rank.  pack: the j-th block of `rank` goes to packed[j * 256 ..], one workgroup per block, rows of
+// 16 pixels (256 contiguous bytes); unpack: the reverse, into the accumulation buffer.  Pixels of an edge block outside
+// the tile are packed as zeros and skipped on the way back.
+struct BlockPart { uint32_t tile_x0, tile_y0, tile_w, tile_h, blocks_x, width, rank, world; };
+PT_DEV bool block_pixel(const BlockPart& B, uint32_t j, uint32_t p, size_t& pix) {
+    const uint32_t blk = j * B.world + B.rank, bx = blk % B.blocks_x, by = blk / B.blocks_x;
+    const uint32_t tx = bx * 16u + (p & 15u), ty = by * 16u + (p >> 4);
+    pix = (size_t)(B.tile_y0 + ty) * B.width + B.tile_x0 + tx;
+    return tx < B.tile_w && ty < B.tile_h;
+}
+extern "C" __global__ void __launch_bounds__(256) ptx_pack_blocks_kernel(const float4* accum, float4* packed, const BlockPart B) {
+    size_t pix;
+    const bool in = block_pixel(B, blockIdx.x, threadIdx.x, pix);
+    packed[(size_t)blockIdx.x * 256u + threadIdx.x] = in ? accum[pix] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+extern "C" __global__ void __launch_bounds__(256) ptx_unpack_blocks_kernel(float4* accum, const float4* packed, const BlockPart B) {
+    size_t pix;
+    if (block_pixel(B, blockIdx.x, threadIdx.x, pix)) accum[pix] = packed[(size_t)blockIdx.x * 256u + threadIdx.x];
+}
+
 // Post-process pass: one 16 x (16 ROWS)-pixel tile per workgroup, ROWS vertically adjacent pixels per thread (4 for chains
 // with an oil painting, whose pixels then share their columns; 1 otherwise: more pixels per thread cost the pointwise
 // chains 3-8 % in registers).  TILE: the tile and a halo of `halo` texels are staged in LDS (clamped to the image
@@ -1009,6 +1039,7 @@ struct ptx_ctx {
     bool plain_mesh = false;      // wave-scheduled, no marched figures, shallow tree: the scenes whose paths cost least
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
     const char* last_kernel = nullptr;  // the trace kernel of the latest launch since the scene was uploaded
+    std::string last_info;              // ... and what else the launch policy chose for it (ptx_last_launch_info)
     // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
     struct Options {
         int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
@@ -1660,6 +1691,7 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     c->sc = sc;
     c->have_scene = true;
     c->last_kernel = nullptr;
+    c->last_info.clear();
     c->type_mask = type_mask;
     if ((rc = configure(c))) { free_scene(c); return rc; }
     return PTX_OK;
@@ -1912,6 +1944,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     const uint32_t ranges = zero_based ? ranges_wanted : 1u;
     if (zero_based) kernel = ptx_trace_kernel_lds_ranged;  // same LDS, same occupancy
     c->last_kernel = trace_kernel_label(kernel);
+    const uint32_t whole_claim_tile = P.claim_tile;
     uint32_t chunk = n;
     size_t frame_pixels = 0;
     uint32_t depth = 1;
@@ -1937,6 +1970,25 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         if (!c->barrier) HIP_TRY(c, hipEventCreateWithFlags(&c->barrier, hipEventDisableTiming));
     } else {
         c->order_dirty = true;
+    }
+    {
+        // what was chosen, for profiles, bench lines and the policy tests (ptx_last_launch_info); the part before ';' does not
+        // depend on the device's size
+        uint32_t tile0 = whole_claim_tile;
+        if (split && !c->opt.claim_tile) {
+            const uint32_t m0 = n < chunk ? n : chunk;
+            tile0 = !frac ? (P.n_blocks >= 16384u ? 128u : 64u) : (m0 >= 64u ? 256u : 128u);
+            if (c->plain_mesh && sched) {
+                const uint32_t per = (P.n_blocks * 256u * m0 / 49152u + 63u) & ~63u;
+                tile0 = per < 64u ? 64u : (per > 512u ? 512u : per);
+            }
+        }
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s jobs=%s claim_tile=%u counters=%u guided=%u paced=%u pool=%u flights=%u chunk=%u lds_stack=%u; grid=%u",
+                 c->last_kernel, sorted ? "pools" : (split ? "samples" : "pixels"), claim ? tile0 : 0u, claim ? ranges : 0u,
+                 claim && tile0 > 1u ? guided_k : 0u, claim && tile0 > 1u ? paced_m : 0u, sorted ? P.pool_m : 0u, split ? depth : 0u, chunk,
+                 P.sc.lds_stack_entries, grid);
+        c->last_info = buf;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!fixed) {
@@ -2199,6 +2251,26 @@ int ptx_comm_free(ptx_ctx* c) {
     return comm_release(c);
 }
 
+// Runs `body` (which returns the first failing ncclResult_t of its sends and receives) between ncclGroupStart and
+// ncclGroupEnd.  The group is closed on every path: a call that failed inside an open group must not leave the
+// communicator waiting for the rest of it.
+extern "C++" template <class F>
+static int nccl_grouped(ptx_ctx* c, coll::Api* a, const char* what, F body) {
+    NCCL_TRY(c, a, a->GroupStart());
+    const ncclResult_t inside = body();
+    const ncclResult_t closed = a->GroupEnd();
+    if (inside != ncclSuccess) return fail(c, PTX_ERR_HIP, std::string(what) + ": " + a->GetErrorString(inside));
+    if (closed != ncclSuccess) return fail(c, PTX_ERR_HIP, std::string(what) + ": ncclGroupEnd: " + a->GetErrorString(closed));
+    return PTX_OK;
+}
+
+void ptx_slice_of(uint64_t n_pixels, uint32_t world, uint32_t rank, uint64_t* first, uint64_t* count) {
+    uint64_t f = 0, k = 0;
+    if (world > 0u && rank < world) coll::slice_of(n_pixels, world, rank, &f, &k);
+    if (first) *first = f;
+    if (count) *count = k;
+}
+
 int ptx_merge_sample_split(ptx_ctx* c, const uint32_t* counts, const ptx_camera* cam) {
     if (c) c->order_dirty = true;
     if (!c || !counts || !cam) return PTX_ERR_BAD_ARG;
@@ -2228,26 +2300,33 @@ int ptx_merge_sample_split(ptx_ctx* c, const uint32_t* counts, const ptx_camera*
         if (with_m2) HIP_TRY(c, hipMemcpyAsync(recv_m(rank), c->m2 + my_first * 3u, my_cnt * 12u, hipMemcpyDeviceToDevice, st));
     }
     if (world > 1u) {
-        NCCL_TRY(c, a, a->GroupStart());
-        for (uint32_t j = 0; j < world; j++) {
-            if (j == rank) continue;
-            uint64_t f, k;
-            coll::slice_of(n, world, j, &f, &k);
-            if (k) NCCL_TRY(c, a, a->Send(acc + f * 4u, k * 4u, ncclFloat, (int)j, c->comm, st));
-            if (my_cnt) NCCL_TRY(c, a, a->Recv(recv_a(j), my_cnt * 4u, ncclFloat, (int)j, c->comm, st));
-            if (with_m2) {
-                if (k) NCCL_TRY(c, a, a->Send(c->m2 + f * 3u, k * 3u, ncclFloat, (int)j, c->comm, st));
-                if (my_cnt) NCCL_TRY(c, a, a->Recv(recv_m(j), my_cnt * 3u, ncclFloat, (int)j, c->comm, st));
+        const int rc = nccl_grouped(c, a, "ptx_merge_sample_split: slice exchange", [&]() -> ncclResult_t {
+            ncclResult_t r = ncclSuccess;
+            for (uint32_t j = 0; j < world && r == ncclSuccess; j++) {
+                if (j == rank) continue;
+                uint64_t f, k;
+                coll::slice_of(n, world, j, &f, &k);
+                if (k) r = a->Send(acc + f * 4u, k * 4u, ncclFloat, (int)j, c->comm, st);
+                if (my_cnt && r == ncclSuccess) r = a->Recv(recv_a(j), my_cnt * 4u, ncclFloat, (int)j, c->comm, st);
+                if (with_m2) {
+                    if (k && r == ncclSuccess) r = a->Send(c->m2 + f * 3u, k * 3u, ncclFloat, (int)j, c->comm, st);
+                    if (my_cnt && r == ncclSuccess) r = a->Recv(recv_m(j), my_cnt * 3u, ncclFloat, (int)j, c->comm, st);
+                }
             }
-        }
-        NCCL_TRY(c, a, a->GroupEnd());
+            return r;
+        });
+        if (rc) return rc;
     }
-    // 2. Chan's update in fixed rank order: partial 0 is the start, 1, 2, ... are folded in
+    // 2. Chan's update in fixed rank order.  A rank that holds no samples (counts[r] == 0) contributes nothing, whatever its
+    // buffers hold: the first rank with samples is the start, the later ones are folded in.  (No rank with samples: rank 0's slice.)
     if (my_cnt) {
-        HIP_TRY(c, hipMemcpyAsync(acc + my_first * 4u, recv_a(0), my_cnt * 16u, hipMemcpyDeviceToDevice, st));
-        if (with_m2) HIP_TRY(c, hipMemcpyAsync(c->m2 + my_first * 3u, recv_m(0), my_cnt * 12u, hipMemcpyDeviceToDevice, st));
-        uint64_t n_a = counts[0];
-        for (uint32_t r = 1; r < world; r++) {
+        uint32_t r0 = 0u;
+        while (r0 + 1u < world && counts[r0] == 0u) r0++;
+        if (counts[r0] == 0u) r0 = 0u;
+        HIP_TRY(c, hipMemcpyAsync(acc + my_first * 4u, recv_a(r0), my_cnt * 16u, hipMemcpyDeviceToDevice, st));
+        if (with_m2) HIP_TRY(c, hipMemcpyAsync(c->m2 + my_first * 3u, recv_m(r0), my_cnt * 12u, hipMemcpyDeviceToDevice, st));
+        uint64_t n_a = counts[r0];
+        for (uint32_t r = r0 + 1u; r < world; r++) {
             if (counts[r] == 0u) continue;
             hipLaunchKernelGGL(ptx_merge_kernel, dim3((uint32_t)((my_cnt + 255u) / 256u)), dim3(256), 0, st, c->accum, with_m2 ? c->m2 : nullptr, c->out,
                                (uint32_t)my_first, (uint32_t)my_cnt, (float)n_a, (const float4*)recv_a(r), with_m2 ? (const float*)recv_m(r) : nullptr,
@@ -2258,19 +2337,22 @@ int ptx_merge_sample_split(ptx_ctx* c, const uint32_t* counts, const ptx_camera*
     }
     // 3. the merged slices go to everyone
     if (world > 1u) {
-        NCCL_TRY(c, a, a->GroupStart());
-        for (uint32_t j = 0; j < world; j++) {
-            if (j == rank) continue;
-            uint64_t f, k;
-            coll::slice_of(n, world, j, &f, &k);
-            if (my_cnt) NCCL_TRY(c, a, a->Send(acc + my_first * 4u, my_cnt * 4u, ncclFloat, (int)j, c->comm, st));
-            if (k) NCCL_TRY(c, a, a->Recv(acc + f * 4u, k * 4u, ncclFloat, (int)j, c->comm, st));
-            if (with_m2) {
-                if (my_cnt) NCCL_TRY(c, a, a->Send(c->m2 + my_first * 3u, my_cnt * 3u, ncclFloat, (int)j, c->comm, st));
-                if (k) NCCL_TRY(c, a, a->Recv(c->m2 + f * 3u, k * 3u, ncclFloat, (int)j, c->comm, st));
+        const int rc = nccl_grouped(c, a, "ptx_merge_sample_split: merged slices", [&]() -> ncclResult_t {
+            ncclResult_t r = ncclSuccess;
+            for (uint32_t j = 0; j < world && r == ncclSuccess; j++) {
+                if (j == rank) continue;
+                uint64_t f, k;
+                coll::slice_of(n, world, j, &f, &k);
+                if (my_cnt) r = a->Send(acc + my_first * 4u, my_cnt * 4u, ncclFloat, (int)j, c->comm, st);
+                if (k && r == ncclSuccess) r = a->Recv(acc + f * 4u, k * 4u, ncclFloat, (int)j, c->comm, st);
+                if (with_m2) {
+                    if (my_cnt && r == ncclSuccess) r = a->Send(c->m2 + my_first * 3u, my_cnt * 3u, ncclFloat, (int)j, c->comm, st);
+                    if (k && r == ncclSuccess) r = a->Recv(c->m2 + f * 3u, k * 3u, ncclFloat, (int)j, c->comm, st);
+                }
             }
-        }
-        NCCL_TRY(c, a, a->GroupEnd());
+            return r;
+        });
+        if (rc) return rc;
     }
     // 4. the rgba8 image of the whole frame from the merged means
     hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, st, c->accum, c->out, 0u, (uint32_t)n, *cam);
@@ -2287,9 +2369,55 @@ int ptx_assemble_tiles(ptx_ctx* c, const ptx_camera* cam) {
     if (!a) return fail(c, PTX_ERR_UNSUPPORTED, "ptx_assemble_tiles: " + coll::api_error());
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t n = (uint64_t)c->w * c->h;
-    // the ranks' buffers are disjoint (untouched pixels are zero), so the sum is exact
-    if (c->comm_world > 1) NCCL_TRY(c, a, a->AllReduce(c->accum, c->accum, n * 4u, ncclFloat, ncclSum, c->comm, c->stream));
-    hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, c->stream, c->accum, c->out, 0u, (uint32_t)n, *cam);
+    const uint32_t world = (uint32_t)c->comm_world, rank = (uint32_t)c->comm_rank;
+    hipStream_t st = c->stream;
+    if (world > 1u && c->part_world == world && c->part_rank == rank) {
+        // Ownership is known (ptx_set_partition with the communicator's rank and size): every rank packs the blocks it traced,
+        // sends them to every peer and receives the peers' -- an all-gather of uneven shares, every peer link busy at once,
+        // (world - 1) / world of the frame in and 1 / world of it out per link pair, half of what a ring all-reduce of the whole
+        // buffer moves -- and unpacks them into its accumulation buffer.  Exact: no arithmetic is done on the pixels.
+        BlockPart B;
+        B.tile_x0 = c->tx0; B.tile_y0 = c->ty0; B.tile_w = c->tw; B.tile_h = c->th;
+        B.blocks_x = (c->tw + 15u) / 16u; B.width = c->w; B.world = world;
+        const uint32_t total_blocks = B.blocks_x * ((c->th + 15u) / 16u);
+        auto blocks_of = [&](uint32_t r) { return total_blocks > r ? (total_blocks - r + world - 1u) / world : 0u; };
+        std::vector<size_t> first(world + 1u, 0);
+        for (uint32_t r = 0; r < world; r++) first[r + 1u] = first[r] + (size_t)blocks_of(r) * 256u;
+        const size_t need = first[world] * 4u;  // floats
+        if (need > c->xchg_floats) {
+            if (c->xchg) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->xchg); c->xchg = nullptr; c->xchg_floats = 0; }
+            HIP_TRY(c, hipMalloc((void**)&c->xchg, (need ? need : 4) * sizeof(float)));
+            c->xchg_floats = need;
+        }
+        float4* packed = (float4*)c->xchg;
+        const uint32_t mine = blocks_of(rank);
+        if (mine) {
+            B.rank = rank;
+            hipLaunchKernelGGL(ptx_pack_blocks_kernel, dim3(mine), dim3(256), 0, st, (const float4*)c->accum, packed + first[rank], B);
+            HIP_TRY(c, hipGetLastError());
+        }
+        const int rc = nccl_grouped(c, a, "ptx_assemble_tiles: block exchange", [&]() -> ncclResult_t {
+            ncclResult_t r = ncclSuccess;
+            for (uint32_t j = 0; j < world && r == ncclSuccess; j++) {
+                if (j == rank) continue;
+                if (mine) r = a->Send(packed + first[rank], (size_t)mine * 1024u, ncclFloat, (int)j, c->comm, st);
+                if (blocks_of(j) && r == ncclSuccess) r = a->Recv(packed + first[j], (size_t)blocks_of(j) * 1024u, ncclFloat, (int)j, c->comm, st);
+            }
+            return r;
+        });
+        if (rc) return rc;
+        for (uint32_t j = 0; j < world; j++) {
+            if (j == rank || blocks_of(j) == 0u) continue;
+            B.rank = j;
+            hipLaunchKernelGGL(ptx_unpack_blocks_kernel, dim3(blocks_of(j)), dim3(256), 0, st, c->accum, (const float4*)(packed + first[j]), B);
+            HIP_TRY(c, hipGetLastError());
+        }
+    } else if (world > 1u) {
+        // Any other disjoint split (tiles set with ptx_set_tile, a partition that is not the communicator's): the ranks' buffers
+        // are disjoint and untouched pixels are zero, so one SUM all-reduce of the whole buffer is exact.
+        NCCL_TRY(c, a, a->AllReduce(c->accum, c->accum, n * 4u, ncclFloat, ncclSum, c->comm, st));
+    }
+    hipLaunchKernelGGL(ptx_tonemap_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, st, c->accum, c->out, 0u, (uint32_t)n, *cam);
     HIP_TRY(c, hipGetLastError());
     return PTX_OK;
 }
@@ -2467,6 +2595,8 @@ const char* ptx_trace_kernel_name(const ptx_ctx* c) {
     if (c->sched) return lds ? "ptx_sched_kernel_lds_frac" : "ptx_sched_kernel_frac";
     return lds ? (frac ? "ptx_trace_kernel_lds_frac" : "ptx_trace_kernel_lds") : (frac ? "ptx_trace_kernel_frac" : "ptx_trace_kernel");
 }
+
+const char* ptx_last_launch_info(const ptx_ctx* c) { return c ? c->last_info.c_str() : ""; }
 
 int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
     if (!c || !out) return PTX_ERR_BAD_ARG;

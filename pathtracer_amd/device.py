@@ -212,6 +212,10 @@ class PathTracer:
     def kernel_name(self) -> str:
         return self.lib.ptx_trace_kernel_name(self.h).decode()
 
+    def launch_info(self) -> str:
+        """What the launch policy chose for the latest trace call: kernel, job form, reservation size, counters, pools, flights."""
+        return self.lib.ptx_last_launch_info(self.h).decode()
+
     def kernel_time(self) -> Tuple[float, int]:
         ms, n = C.c_float(), C.c_uint32()
         self._ck(self.lib.ptx_kernel_time(self.h, C.byref(ms), C.byref(n)), "ptx_kernel_time")

@@ -119,6 +119,25 @@ def test_pools_with_short_bounce_limits(pt, max_bounces):
     assert a[4][1] == (0 if max_bounces == 0 else a[4][1])
 
 
+@pytest.mark.parametrize("w,h,n,pool", [(8, 16, 8, 256), (8, 16, 5, 256), (24, 8, 8, 512), (40, 24, 16, 256)])
+def test_a_reservation_wholly_outside_the_tile_does_not_end_the_workgroup(pt, w, h, n, pool):
+    """One-block and few-block frames whose right / bottom quadrants lie outside the tile: 64 * n consecutive jobs that
+    job_pixel skips.  With every path ending in its first round (max_bounces 1) the pool is empty when such a run is
+    reserved; the workgroup has to go on reserving until the launch's last jobs have been handed out."""
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    sb = hp.prepare_fixture(fixture("cornell_box"))
+    cam = sc.camera(w, h)
+    cam[0]["max_bounces"] = 1
+    ref = orc.render(orc.OracleScene(sb), cam, n, want_m2=True, counters=True)
+    c = ref["counters"]
+    want = (ref["accum"], ref["m2"], ref["primary_id"], ref["rgba8"], (c["paths"], c["bounces"], c["shadow_rays"]))
+    a = _render(pt, sc, cam, w, h, [(0, 1, n)], sorted_pool=0)
+    b = _render(pt, sc, cam, w, h, [(0, 1, n)], sorted_pool=1, pool_paths=pool, pool_over=4)
+    assert "sorted" in b[5]
+    assert _same(a, want)
+    assert _same(b, want), (w, h, n, pool)
+
+
 def test_launch_lengths_pick_the_kernel_form(pt):
     """Launches of up to four samples keep lane-owned paths (they overlap with their neighbours); longer ones trace from pools."""
     sc = host.Scene.from_fixture(fixture("cornell_box")).build()
