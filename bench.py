@@ -3,16 +3,20 @@
 python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|teapot|fractals|all_mesh] [--spp-per-step S]
 
 A step is one batched launch of the hot path: S samples for every pixel of the workload's frame, inputs
-(scene, accumulation buffer) resident in HBM.  N > 1 (one process per GPU under torch.distributed.run):
-sample split — every rank renders the full frame for its own frame-index range (weak scaling: per-GPU
-work is fixed), and the per-GPU Welford moments are merged once at the end of the timed region with
-Chan's formula over RCCL.  Rank 0 prints ONE JSON line.
+(scene, accumulation buffer) resident in HBM.  N > 1 (one process per GPU under torch.distributed.run; started
+without it, this script starts that launcher itself as a child process): sample split -- every rank renders the
+full frame for its own frame-index range (weak scaling: per-GPU work is fixed), and the per-GPU Welford moments
+are merged once at the end of the timed region with Chan's formula over RCCL; a second, fixed-total-work leg
+(the same 1024 samples per pixel whatever N: strong scaling) follows and is reported beside it.  Rank 0 prints
+ONE JSON line.  At N = 1 the default run also times the other three workloads briefly (teapot 4K, fractals,
+all.yaml + 10 M triangles) and attaches them as `other_workloads`, each with its own roofline and CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,8 +32,11 @@ WORKLOADS = {
     "fractals": ("fractals", 1920, 1080, 128, "fractals.yaml 1920x1080 Mandelbulb/Julia ray-march"),
     "all_mesh": ("all", 1920, 1080, 8, "all.yaml + synthetic height-field mesh 1920x1080"),
 }
+# bounded CPU samples (whole frames, 5-30 s of work on the box's host cores): frames per workload
+CPU_FRAMES = {"cornell": 64, "teapot": 24, "fractals": 8, "all_mesh": 4}
 PEAK_FP32_VALU_TFLOPS = 157.3  # packed v_pk_fma_f32; 78.6 for one FMA per lane per clock
 PEAK_HBM_GBS = 8000.0
+METRIC = "Mpaths/s at 1080p (1/2/4/8 GPUs) + % FP32 VALU peak; image RMSE vs ref"
 
 
 def cpu_baseline(scene, cam, label: str, spp: int, tile=None):
@@ -84,68 +91,94 @@ def image_rmse(pt, cam, spp: int, ref: dict, tile=None):
             "frames": spp, "pixels": int(tw * th)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=list(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=0)
-    ap.add_argument("--mesh-quads", type=int, default=2236, help="all_mesh: quads per side (2236 -> 10.0 M triangles)")
-    ap.add_argument("--partition", default="", choices=["", "samples", "tiles"],
-                    help="N > 1: sample split (weak scaling, default) or interleaved 16x16 tiles (strong scaling, default for teapot)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
-                    help="ptx_set_option setting for measurement runs (e.g. flights=1: launches one after the other), recorded in config.options")
-    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
-                    help="N > 1: the multi-GPU epilogue by the library's own RCCL exchange (ptx_merge_sample_split / ptx_assemble_tiles, default) "
-                         "or by the same steps over torch.distributed collectives")
-    args = ap.parse_args()
+def relaunch_under_torchrun(args) -> int:
+    """N > 1 without a launcher: this process has made no GPU call yet; it starts one process per GPU as a child
+    (torch.distributed.run, rendezvous on 127.0.0.1), relays the ranks' output and returns the child's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py --gpus N with N > 1 must be launched as one process per GPU (torch.distributed.run)", file=sys.stderr)
-        sys.exit(2)
 
-    import torch
+class Dist:
+    """The launcher's process group (RCCL, or gloo to rehearse with ranks sharing GPUs) and this rank's place in it."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        import torch
+        self.torch = torch
+        # PTX355_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs).
+        self.backend = os.environ.get("PTX355_DIST_BACKEND", "nccl")
+        self.dev_index = self.local_rank % max(torch.cuda.device_count(), 1) if self.backend != "nccl" else self.local_rank
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            torch.cuda.set_device(self.dev_index)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device(f"cuda:{self.dev_index}"))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.device = torch.device(f"cuda:{self.dev_index}")
+
+    def barrier(self, pt):
+        pt.sync()
+        if self.dist is not None:
+            self.torch.cuda.synchronize(self.device)
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.device)
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.dist is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v: float) -> float:
+        if self.dist is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def run_workload(name: str, args, D: Dist, steps: int, warmup: int, spp_override: int = 0, with_cpu: bool = True, strong_leg: bool = False) -> dict:
+    """One workload: scene build + upload, warm-up, the timed region, then (outside it) the CPU baseline, the image RMSE
+    and the roofline figures.  Returns the bench line as a dict (rank 0; None on the other ranks)."""
     from pathtracer_amd import host, multigpu
     from pathtracer_amd.device import PathTracer
-
-    dist = None
-    # PTX355_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs).
-    backend = os.environ.get("PTX355_DIST_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    device = torch.device(f"cuda:{dev_index}")
-
-    fx_name, w, h, spp_default, label = WORKLOADS[args.workload]
-    spp = args.spp_per_step or spp_default
+    rank, world, dist, device = D.rank, D.world, D.dist, D.device
+    fx_name, w, h, spp_default, label = WORKLOADS[name]
+    spp = spp_override or spp_default
     scene = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", f"{fx_name}.npz"))
-    if args.workload == "all_mesh":
+    if name == "all_mesh":
         scene.append_heightfield(args.mesh_quads)
-    pt = PathTracer(dev_index)
+    pt = PathTracer(D.dev_index)
     options = {}
     for kv in args.opt:
         k, v = kv.split("=", 1)
         pt.set_option(k, int(v))
         options[k] = int(v)
     # the mesh scene's tree is built on the GPU (ptx_bvh_build: the same arrays as the host builder, 60x sooner)
-    gpu_bvh = args.workload == "all_mesh"
+    gpu_bvh = name == "all_mesh"
     t0 = time.perf_counter()
     scene.build(decode_textures=False, tracer=pt if gpu_bvh else None)
     build_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     scene.upload_to(pt)
     upload_s = time.perf_counter() - t0
-    partition = args.partition or ("tiles" if args.workload == "teapot" else "samples")
+    partition = args.partition or ("tiles" if name == "teapot" else "samples")
     tiles = world > 1 and partition == "tiles"
     if world > 1 and not tiles:
         pt.enable_moments(True)
@@ -156,63 +189,71 @@ def main():
         pt.set_partition(rank, world)  # this rank's interleaved 16x16 blocks; every rank traces the same frames
     cam = scene.camera(w, h)
 
-    def epilogue(samples_per_rank):
+    def epilogue(counts):
         if args.exchange == "library":
-            (pt.assemble_tiles(cam) if tiles else pt.merge_sample_split([samples_per_rank] * world, cam))
+            (pt.assemble_tiles(cam) if tiles else pt.merge_sample_split(counts, cam))
         elif tiles:
             multigpu.assemble_tiles(pt, dist, device, cam)
         else:
-            multigpu.merge_sample_split(pt, dist, device, [samples_per_rank] * world, cam)
-
-    def barrier():
-        pt.sync()
-        if dist is not None:
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            torch.cuda.synchronize(device)
+            multigpu.merge_sample_split(pt, dist, device, counts, cam)
 
     # sample split: rank r owns frames [r * steps * spp, (r + 1) * steps * spp), samples counted locally
-    frame0 = 0 if tiles else rank * (args.steps + args.warmup) * spp
-    for i in range(args.warmup):
+    frame0 = 0 if tiles else rank * (steps + warmup) * spp
+    for i in range(warmup):
         pt.trace_n(cam, frame0 + i * spp, 1 + i * spp, spp)
-    if dist is not None and args.warmup > 0:
+    if dist is not None and warmup > 0:
         # the first collectives set up RCCL's channels: keep that out of the timed region
-        epilogue(args.warmup * spp)
+        epilogue([warmup * spp] * world)
     pt.sync()
     pt.clear()
     pt.kernel_time()
-    barrier()
+    D.barrier(pt)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        pt.trace_n(cam, frame0 + (args.warmup + i) * spp, 1 + i * spp, spp)
+    for i in range(steps):
+        pt.trace_n(cam, frame0 + (warmup + i) * spp, 1 + i * spp, spp)
     if dist is not None:
-        epilogue(args.steps * spp)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        epilogue([steps * spp] * world)
+    D.barrier(pt)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     kernel_ms, launches = pt.kernel_time()
-    per_launch = pt.kernel_times()[-args.steps:]
+    per_launch = pt.kernel_times()[-steps:]
+    launch_info = pt.launch_info()
     st = pt.stats()
-    total_paths = w * h * spp * args.steps * (1 if tiles else world)  # tiles: the ranks share one frame
+    total_paths = w * h * spp * steps * (1 if tiles else world)  # tiles: the ranks share one frame
     bounces = st["bounces"]
-    if dist is not None:
-        t = torch.tensor([bounces], dtype=torch.float64, device=device)
-        dist.all_reduce(t)
-        total_bounces = float(t.item())
-    else:
-        total_bounces = float(bounces)
+    total_bounces = D.sum_over_ranks(float(bounces))
 
+    strong = None
+    if strong_leg and world > 1 and not tiles:
+        # Fixed total work: the SAME 1024 samples per pixel (steps x spp) whatever the number of GPUs, each rank tracing its
+        # share of the frame indices in launches of at most `spp`, one merge inside the timed region.
+        total_spp = steps * spp
+        share = multigpu.sample_ranges(total_spp, world)
+        first, cnt = share[rank]
+        pt.clear()
+        D.barrier(pt)
+        t0 = time.perf_counter()
+        done = 0
+        while done < cnt:
+            m = min(spp, cnt - done)
+            pt.trace_n(cam, first + done, 1 + done, m)
+            done += m
+        epilogue([c for _, c in share])
+        D.barrier(pt)
+        s_elapsed = D.max_over_ranks(time.perf_counter() - t0)
+        strong = {"scaling": "strong", "total_spp": total_spp, "spp_per_rank": [c for _, c in share], "value": round(w * h * total_spp / s_elapsed / 1e6, 2),
+                  "unit": "Mpaths/s", "ms_total": round(s_elapsed * 1e3, 3),
+                  "note": "whole-job rate of one 1024-spp render split over the ranks by frame index, merge included; at N = 1 this is the headline run"}
+
+    out = None
     if rank == 0:
         out = {
-            "metric": "Mpaths/s at 1080p (1/2/4/8 GPUs) + % FP32 VALU peak; image RMSE vs ref",
-            "value": round(total_paths / elapsed / 1e6, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+            "metric": METRIC,
+            "value": round(total_paths / elapsed / 1e6, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True,
             "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label, "width": w, "height": h, "spp_per_step": spp, "frames": args.steps * spp,
-                       "partition": "single GPU" if world == 1 else (f"interleaved 16x16 tiles over {world} GPUs + RCCL sum" if tiles
+            "config": {"workload": label, "width": w, "height": h, "spp_per_step": spp, "frames": steps * spp,
+                       "partition": "single GPU" if world == 1 else (f"interleaved 16x16 tiles over {world} GPUs + RCCL block exchange" if tiles
                                                                        else f"sample split over {world} GPUs + RCCL Chan merge"),
                        "exchange": None if world == 1 else args.exchange, "options": options or None,
                        "scene_build_s": round(build_s, 3), "bvh_builder": "gpu" if gpu_bvh else "host", "scene_upload_s": round(upload_s, 3)},
@@ -225,17 +266,18 @@ def main():
             "launches_overlap": bool(len(per_launch) and float(per_launch.min()) <= 0.5 * float(per_launch.mean())),
             "image_rmse_vs_ref": None,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         cpu, flops_per_bounce = None, None
-        if not args.no_cpu_baseline and world == 1:
-            # bounded CPU samples: whole frames, 10-30 s of work on the box's host cores
-            cpu_spp, cpu_tile = {"cornell": (64, None), "teapot": (24, None), "fractals": (8, None), "all_mesh": (4, None)}[args.workload]
-            cpu, cnt, flops, ref = cpu_baseline(scene, cam, label, cpu_spp, cpu_tile)
+        if with_cpu and world == 1:
+            cpu_spp = CPU_FRAMES[name]
+            cpu, cnt, flops, ref = cpu_baseline(scene, cam, label, cpu_spp, None)
             flops_per_bounce = flops / max(cnt["bounces"], 1)
             # the oracle's frames double as the reference image of the metric's RMSE (after the timed region; uses the tracer)
-            out["image_rmse_vs_ref"] = image_rmse(pt, cam, cpu_spp, ref, cpu_tile)
+            out["image_rmse_vs_ref"] = image_rmse(pt, cam, cpu_spp, ref, None)
         avg_ms = kernel_ms / max(launches, 1)
-        roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": pt.kernel_name(),
-                "kernel_avg_ms": round(avg_ms, 3), "launches": launches, "traffic": None}
+        roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_VALU_TFLOPS, "kernel": launch_info.split(" ")[0],
+                "launch": launch_info, "kernel_avg_ms": round(avg_ms, 3), "launches": launches, "traffic": None}
         if flops_per_bounce is not None:
             flops_per_launch = flops_per_bounce * bounces / max(launches, 1)
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -248,7 +290,7 @@ def main():
         roof["hbm_streaming"] = {"bytes_per_launch": stream_bytes, "achieved_gbs": round(stream_bytes / (avg_ms * 1e-3) / 1e9, 3),
                                  "peak_gbs": PEAK_HBM_GBS}
         bf = os.path.join(ROOT, "profiles", "bvh_fetch.json")
-        if args.workload == "all_mesh" and os.path.exists(bf):
+        if name == "all_mesh" and os.path.exists(bf):
             # The mesh workload is bound by dependent BVH record fetches, not by arithmetic: its roofline is the
             # algorithmic record bytes (64 B per node pair visited and per triangle tested, counted by a
             # diagnostic build on this same scene) over the kernel time, against HBM peak.
@@ -257,25 +299,76 @@ def main():
                 per_bounce = b["bytes_per_path_bounce"]
                 ach = per_bounce * bounces / max(launches, 1) / (avg_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": round(ach, 2), "frac": round(ach / PEAK_HBM_GBS, 5),
-                        "traffic": b.get("hbm_bytes_per_launch"), "kernel": pt.kernel_name(), "kernel_avg_ms": round(avg_ms, 3),
+                        "traffic": b.get("hbm_bytes_per_launch"),
+                        "traffic_source": "profiles/bvh_fetch.json: rocprofv3 PMC passes of this command, committed with the source; not measured in this run",
+                        "kernel": launch_info.split(" ")[0], "launch": launch_info, "kernel_avg_ms": round(avg_ms, 3),
                         "launches": launches, "bvh_bytes_per_path_bounce": per_bounce,
                         "valu": {k: roof.get(k) for k in ("achieved", "frac", "flops_per_path_bounce")}}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf))
-                if t.get("workload") == args.workload and t.get("spp_per_step") == spp and roof.get("traffic") is None:
+                t = t.get(name, t) if isinstance(t.get(name), dict) else t
+                if t.get("workload") == name and t.get("spp_per_step") == spp and roof.get("traffic") is None and not options:
                     roof["traffic"] = t.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = "profiles/traffic.json: rocprofv3 PMC passes of this command, committed with the source; not measured in this run"
                     if t.get("valu_issue"):  # what the VALU counters of the committed profile say about this same launch
                         roof["valu_issue_profiled"] = {k: t["valu_issue"][k] for k in ("valu_busy_frac", "lane_utilisation")}
             except Exception:
                 pass
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
     pt.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell", choices=list(WORKLOADS))
+    ap.add_argument("--spp-per-step", type=int, default=0)
+    ap.add_argument("--mesh-quads", type=int, default=2236, help="all_mesh: quads per side (2236 -> 10.0 M triangles)")
+    ap.add_argument("--partition", default="", choices=["", "samples", "tiles"],
+                    help="N > 1: sample split (weak scaling, default) or interleaved 16x16 tiles (strong scaling, default for teapot)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N = 1, default workload: skip the short legs of the other three workloads")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each of those legs")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, sample split: skip the fixed-total-work leg")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="ptx_set_option setting for measurement runs (e.g. flights=1: launches one after the other), recorded in config.options")
+    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
+                    help="N > 1: the multi-GPU epilogue by the library's own RCCL exchange (ptx_merge_sample_split / ptx_assemble_tiles, default) "
+                         "or by the same steps over torch.distributed collectives")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))  # before any GPU call: the ranks are children of this process
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={os.environ.get('WORLD_SIZE')}: the two must agree", file=sys.stderr)
+        sys.exit(2)
+
+    D = Dist()
+    out = run_workload(args.workload, args, D, args.steps, args.warmup, args.spp_per_step, with_cpu=not args.no_cpu_baseline,
+                       strong_leg=not args.no_strong_leg)
+    if D.world == 1 and args.workload == "cornell" and not args.no_other_workloads and not args.opt and not args.spp_per_step:
+        # the other three workloads, briefly, with the same code as --workload <name>: their own roofline, CPU baseline and RMSE
+        others = {}
+        for name in ("teapot", "fractals", "all_mesh"):
+            t0 = time.perf_counter()
+            try:
+                o = run_workload(name, args, D, args.other_steps, 1, 0, with_cpu=not args.no_cpu_baseline)
+                keep = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "gpath_bounce_per_s", "bounces_per_path", "ms_per_step_median",
+                        "launches_overlap", "image_rmse_vs_ref", "roofline", "cpu_baseline")
+                others[name] = {k: o[k] for k in keep}
+                others[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+            except Exception as e:  # noqa: BLE001  a leg that fails must not lose the headline line
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
+        out["other_workloads"] = others
+    if D.rank == 0:
+        print(json.dumps(out), flush=True)
+    D.close()
 
 
 if __name__ == "__main__":

@@ -64,8 +64,22 @@ def build_harness(force: bool = False) -> str:
     return target
 
 
+def build_loopback(force: bool = False) -> str:
+    """tests/loopback/librccl.so.1: the in-process RCCL stand-in the multi-rank GPU tests load (test infrastructure)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "loopback", "rccl_loopback.hip")
+    target = os.path.join(root, "tests", "loopback", "librccl.so.1")
+    if force or _stale(target, [src]):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                               "-Wl,-soname,librccl.so.1", "-o", target, src])
+    return target
+
+
 def build_all(force: bool = False):
-    return build_device(force), build_host(force), build_harness(force)
+    out = build_device(force), build_host(force), build_harness(force)
+    build_loopback(force)
+    return out
 
 
 if __name__ == "__main__":

@@ -834,11 +834,15 @@ extern "C" __global__ void ptx_merge_kernel(float4* accum, float* m2, uint32_t* 
     V3 ma = v3(a.x, a.y, a.z), mb = v3(b.x, b.y, b.z);
     V3 d = mb - ma;
     V3 m = ma + d * wb;
-    if (n_a == 0.0f) m = mb;  // an untouched accumulator contributes nothing
+    if (n_a == 0.0f) m = mb;  // an accumulator without samples contributes nothing, whatever it holds
     if (m2 && o_m2) {
-        m2[p * 3] = m2[p * 3] + o_m2[(size_t)i * 3] + d.x * d.x * wab;
-        m2[p * 3 + 1] = m2[p * 3 + 1] + o_m2[(size_t)i * 3 + 1] + d.y * d.y * wab;
-        m2[p * 3 + 2] = m2[p * 3 + 2] + o_m2[(size_t)i * 3 + 2] + d.z * d.z * wab;
+        if (n_a == 0.0f) {
+            m2[p * 3] = o_m2[(size_t)i * 3]; m2[p * 3 + 1] = o_m2[(size_t)i * 3 + 1]; m2[p * 3 + 2] = o_m2[(size_t)i * 3 + 2];
+        } else {
+            m2[p * 3] = m2[p * 3] + o_m2[(size_t)i * 3] + d.x * d.x * wab;
+            m2[p * 3 + 1] = m2[p * 3 + 1] + o_m2[(size_t)i * 3 + 1] + d.y * d.y * wab;
+            m2[p * 3 + 2] = m2[p * 3 + 2] + o_m2[(size_t)i * 3 + 2] + d.z * d.z * wab;
+        }
     }
     accum[p] = make_float4(m.x, m.y, m.z, 1.0f);
     out_rgba8[p] = tonemap_rgba8(cam, m);
