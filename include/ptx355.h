@@ -107,8 +107,12 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   split_samples   1 (default) / 0: sample-granular jobs + fold, launches that overlap (see ptx_trace_n)
  *   split_small     -1 every launch (default), else: launches of up to this many samples use them, longer ones fold in the
  *                   lane (fractal scenes on the wave-scheduled kernels always use them)
- *   idle_whole      1 (default) / 0: a one-sample launch that finds the previous launch finished (a host that reads every frame
- *                   back) runs whole-pixel jobs, as it has no neighbour to overlap with (lockstep kernels, meshes without lights)
+ *   host_waits_per_frame  -1 (default) by the call sequence, 0, 1: a one-sample launch of a host that waits for every frame (reads each
+ *                   frame back before it asks for the next, as the reference presents every frame) has no neighbour to overlap
+ *                   with and runs whole-pixel jobs: no staging, no fold kernel (lockstep kernels, meshes without lights).  By
+ *                   default a launch counts as such when the host has made a synchronising call (ptx_sync, ptx_read_*,
+ *                   ptx_kernel_time*) since the launch before it, and before that one as well; 1 declares every one-sample
+ *                   launch to be one, 0 none.  Never a function of host timing.  (idle_whole 0 / 1 = 0 / -1: the earlier name.)
  *   split_chunk     0 = bounded by the staging buffer, else samples per chunk
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes
  *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with
@@ -288,6 +292,10 @@ const char* ptx_trace_kernel_name(const ptx_ctx* ctx);
  * lds_stack=..; grid=..".  The part before ';' depends on the scene, the options and the launch length only, not on the
  * device's size or on host timing.  "" before the first launch on the uploaded scene. */
 const char* ptx_last_launch_info(const ptx_ctx* ctx);
+/* The same description (the part before ';') of what a ptx_trace_n of n samples would run now, without launching: the row of
+ * the launch policy's table for that length, resolved for the current frame size, tile, partition and call sequence.
+ * "" before ptx_upload_scene / ptx_resize. */
+const char* ptx_launch_plan(ptx_ctx* ctx, uint32_t n);
 
 /* Sum of the trace kernels' durations (HIP events on the context's stream) and their count since the
  * last call; synchronises. */

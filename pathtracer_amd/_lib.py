@@ -54,6 +54,7 @@ SYMBOLS = [
     ("ptx_read_stats", C.c_int, [_P, C.POINTER(PtxStats)]),
     ("ptx_trace_kernel_name", C.c_char_p, [_P]),
     ("ptx_last_launch_info", C.c_char_p, [_P]),
+    ("ptx_launch_plan", C.c_char_p, [_P, _U]),
     ("ptx_kernel_time", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U)]),
     ("ptx_kernel_times", C.c_int, [_P, _P, _U, C.POINTER(_U)]),
     ("ptx_kat_math", C.c_int, [_P, C.c_int, _U, _P, _P, _P]),

@@ -226,6 +226,100 @@ PT_DEV float pow_(float x, float y) { return exp2_(y * log2_(x)); }
 
 }  // namespace dm
 
+
+// ---- two evaluations side by side --------------------------------------------------------------------------------
+// gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- two independent IEEE binary32 operations on a register
+// pair -- at the rate of one unpacked operation, so two evaluations of one polynomial cost little more than one.  The
+// functions below are dm::sincos_, dm::log2_, dm::exp2_ and dm::pow_ on TWO arguments at once: element k of every result
+// is, operation for operation, what the scalar function computes for element k (the same constants, the same fma
+// chains, the same roundings, selects where the scalar code branches), so results are bit-identical; the distance
+// estimators' inner iterations (figures_dev.h) use them for their pairs of calls.  The compiler's own vectoriser does not
+// form these pairs (forced with -slp-threshold it loses more in moves than it gains).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+namespace dm2 {
+PT_DEV f2 mk(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+PT_DEV f2 splat(float v) { return mk(v, v); }
+PT_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+PT_DEV f2 sel(i2 cond, f2 a, f2 b) { return mk(cond.x ? a.x : b.x, cond.y ? a.y : b.y); }  // cond: 0 / non-zero per element
+PT_DEV f2 u2f(u2 u) { return mk(__uint_as_float(u.x), __uint_as_float(u.y)); }
+PT_DEV u2 f2u(f2 f) { u2 r; r.x = __float_as_uint(f.x); r.y = __float_as_uint(f.y); return r; }
+
+PT_DEV void sincos2(f2 x, f2* s_out, f2* c_out) {  // dm::sincos_
+    f2 k = __builtin_elementwise_rint(x * 0.63661977236758134f);
+    f2 r = fma2(-k, splat(1.5703125f), x);
+    r = fma2(-k, splat(4.837512969970703125e-4f), r);
+    r = fma2(-k, splat(7.54978995489188216e-8f), r);
+    const i2 q = __builtin_convertvector(k, i2) & 3;
+    f2 z = r * r;
+    f2 sp = fma2(z, fma2(z, splat(-1.9515295891e-4f), splat(8.3321608736e-3f)), splat(-1.6666654611e-1f));
+    f2 s = fma2(r * z, sp, r);
+    f2 cp = fma2(z, fma2(z, splat(2.443315711809948e-5f), splat(-1.388731625493765e-3f)), splat(4.166664568298827e-2f));
+    f2 c = fma2(z * z, cp, fma2(splat(-0.5f), z, splat(1.0f)));
+    f2 so = sel(q & 1, c, s), co = sel(q & 1, s, c);
+    so = sel(q & 2, -so, so);
+    co = sel((q + 1) & 2, -co, co);
+    *s_out = so;
+    *c_out = co;
+}
+
+// dm::log2_ for x > 0 finite; the other inputs (zero, negative, infinity, NaN) are patched in by selects from the scalar code's answers
+PT_DEV f2 log2_2(f2 x0) {
+    const i2 tiny = x0 < 1.17549435e-38f;
+    f2 x = sel(tiny, x0 * 8388608.0f, x0);
+    const u2 b = f2u(x);
+    i2 e = __builtin_convertvector((b >> 23) & 0xffu, i2) - 126 + (tiny & -23);
+    f2 m = u2f((b & 0x007fffffu) | 0x3f000000u);
+    const i2 low = m < 0.70710678118654752440f;
+    e = e + low;  // a true comparison is -1 per element
+    m = sel(low, m + m - 1.0f, m - 1.0f);
+    f2 z = m * m;
+    f2 p = fma2(m, splat(7.0376836292e-2f), splat(-1.1514610310e-1f));
+    p = fma2(p, m, splat(1.1676998740e-1f));
+    p = fma2(p, m, splat(-1.2420140846e-1f));
+    p = fma2(p, m, splat(1.4249322787e-1f));
+    p = fma2(p, m, splat(-1.6668057665e-1f));
+    p = fma2(p, m, splat(2.0000714765e-1f));
+    p = fma2(p, m, splat(-2.4999993993e-1f));
+    p = fma2(p, m, splat(3.3333331174e-1f));
+    f2 y = (p * m) * z;
+    y = fma2(splat(-0.5f), z, y);
+    const f2 fe = __builtin_convertvector(e, f2);
+    const f2 lnm = m + y;
+    f2 r = fma2(lnm, splat(1.44269504088896341f), fe);
+    // dm::log2_'s early returns
+    r = sel(x0 == __builtin_inff(), x0, r);
+    r = sel(x0 > 0.0f, r, sel(x0 == 0.0f, splat(-__builtin_inff()), splat(__builtin_nanf(""))));
+    return r;
+}
+
+PT_DEV f2 exp2_2(f2 x) {  // dm::exp2_
+    f2 k = __builtin_elementwise_rint(x);
+    f2 f = x - k;
+    f2 p = fma2(f, splat(1.535336188319500e-4f), splat(1.339887440266574e-3f));
+    p = fma2(p, f, splat(9.618437357674640e-3f));
+    p = fma2(p, f, splat(5.550332471162809e-2f));
+    p = fma2(p, f, splat(2.402264791363012e-1f));
+    p = fma2(p, f, splat(6.931472028550421e-1f));
+    p = fma2(p, f, splat(1.0f));
+    // the scalar code converts k only for -150 <= x <= 128; outside that range the result is replaced below, so k is clamped
+    // first to keep the conversion defined
+    const f2 kc = __builtin_elementwise_max(__builtin_elementwise_min(k, splat(200.0f)), splat(-200.0f));
+    const i2 ki = __builtin_convertvector(kc, i2);
+    const i2 k1 = ki / 2, k2 = ki - k1;
+    const f2 s1 = u2f(__builtin_convertvector(k1 + 127, u2) << 23);
+    const f2 s2 = u2f(__builtin_convertvector(k2 + 127, u2) << 23);
+    f2 r = (p * s1) * s2;
+    r = sel(x < -150.0f, splat(0.0f), r);
+    r = sel(x > 128.0f, splat(__builtin_inff()), r);
+    r = sel(x != x, x, r);
+    return r;
+}
+PT_DEV f2 pow2(f2 x, f2 y) { return exp2_2(y * log2_2(x)); }  // dm::pow_
+
+}  // namespace dm2
+
 // ---- vector helpers: fixed expression trees ------------------------------------------------------
 // dot = fma chain from the low index; cross = fma(a,b,-(c*d)); madd = fma(d,t,o); vector / scalar is
 // vector * (1 / scalar); everything else is unfused and left to right.

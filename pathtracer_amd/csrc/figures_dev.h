@@ -555,33 +555,45 @@ PT_DEV float sdf_mebius(V3 p, float R) {  // mebius.wgsl:5-36
     float mx = dm::fmax_(du, 0.0f), my = dm::fmax_(dv, 0.0f);
     return dm::sqrt_(dot2(mx, my, mx, my)) + dm::fmin_(dm::fmax_(du, dv), 0.0f);
 }
+// One iteration of the Mandelbulb's w -> w^power + p with its running derivative (mandelbulb.wgsl:11-23): m = |w|^2 on
+// entry, dz is updated.  The two pow calls and the two sincos calls are evaluated side by side (dm2: element for element
+// the scalar functions' operations, so the same bits).
+PT_DEV V3 mandelbulb_iterate(V3 w, V3 p, float m, float power, float& dz) {
+    const float r = dm::sqrt_(m);
+    const f2 pw = dm2::pow2(dm2::mk(m, r), dm2::mk((power - 1.0f) * 0.5f, power));  // pow(m, (power - 1) / 2), pow(r, power)
+    dz = dm::fma_(power * pw.x, dz, 1.0f);
+    const float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
+    const float a = power * dm::atan2_(w.x, w.z);
+    f2 sn, cs;
+    dm2::sincos2(dm2::mk(b, a), &sn, &cs);  // sin / cos of b in .x, of a in .y
+    return p + v3(sn.x * sn.y, cs.x, sn.x * cs.y) * pw.y;
+}
 PT_DEV float sdf_mandelbulb(V3 p, float power, int max_iter) {  // mandelbulb.wgsl:5-30
     V3 w = p;
     float m = dot(w, w);
     float dz = 1.0f;
     for (int i = 0; i < max_iter; i++) {
         PT_SITE(44);
-        dz = dm::fma_(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
-        float r = dm::sqrt_(m);
-        float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
-        float a = power * dm::atan2_(w.x, w.z);
-        float rp = dm::pow_(r, power);
-        float sb, cb, sa, ca;
-        dm::sincos_(b, &sb, &cb);
-        dm::sincos_(a, &sa, &ca);
-        w = p + v3(sb * sa, cb, sb * ca) * rp;
+        w = mandelbulb_iterate(w, p, m, power, dz);
         m = dot(w, w);
         if (m > 256.0f) break;
     }
     float r = dm::sqrt_(m);
     return dm::div_(0.25f * dm::log_(m) * r, dz);
 }
-PT_DEV V4 quat_mult(V4 a, V4 b) {  // julia.wgsl:4-11
+// julia.wgsl:4-11.  Every component is four products summed left to right, each product rounded on its own:
+//   x = ax bx - ay by - az bz - aw bw      y = ax by + ay bx + az bw - aw bz
+//   z = ax bz - ay bw + az bx + aw by      w = ax bw + ay bz - az by + aw bx
+// evaluated two components at a time on register pairs; a subtraction is the addition of the product with one factor negated
+// (exactly the same value), so that both components of a pair add.
+PT_DEV V4 quat_mult(V4 a, V4 b) {
+    const f2 bxy = dm2::mk(b.x, b.y), byx = dm2::mk(b.y, b.x), bzw = dm2::mk(b.z, b.w), bwz = dm2::mk(b.w, b.z);
+    const f2 ax = dm2::splat(a.x), ay_mp = dm2::mk(-a.y, a.y), az_mp = dm2::mk(-a.z, a.z), az_pm = dm2::mk(a.z, -a.z);
+    const f2 aw_mm = dm2::splat(-a.w), aw = dm2::splat(a.w);
+    const f2 xy = ((ax * bxy + ay_mp * byx) + az_mp * bzw) + aw_mm * bwz;
+    const f2 zw = ((ax * bzw + ay_mp * bwz) + az_pm * bxy) + aw * byx;
     V4 r;
-    r.x = a.x * b.x - a.y * b.y - a.z * b.z - a.w * b.w;
-    r.y = a.x * b.y + a.y * b.x + a.z * b.w - a.w * b.z;
-    r.z = a.x * b.z - a.y * b.w + a.z * b.x + a.w * b.y;
-    r.w = a.x * b.w + a.y * b.z - a.z * b.y + a.w * b.x;
+    r.x = xy.x; r.y = xy.y; r.z = zw.x; r.w = zw.y;
     return r;
 }
 PT_DEV float sdf_julia(V3 p, V4 cc, int max_iter) {  // julia.wgsl:13-32
@@ -887,15 +899,7 @@ PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value) {
         if (!done) {
             PT_SITE(44);
             V3 w = v3(f.s[0], f.s[1], f.s[2]), p = v3(f.s[5], f.s[6], f.s[7]);
-            dz = dm::fma_(power * dm::pow_(m, (power - 1.0f) * 0.5f), dz, 1.0f);
-            float r = dm::sqrt_(m);
-            float b = power * dm::acos_(clampf(dm::div_(w.y, r), -1.0f, 1.0f));
-            float a = power * dm::atan2_(w.x, w.z);
-            float rp = dm::pow_(r, power);
-            float sb, cb, sa, ca;
-            dm::sincos_(b, &sb, &cb);
-            dm::sincos_(a, &sa, &ca);
-            w = p + v3(sb * sa, cb, sb * ca) * rp;
+            w = mandelbulb_iterate(w, p, m, power, dz);
             m = dot(w, w);
             f.s[0] = w.x; f.s[1] = w.y; f.s[2] = w.z;
             f.s[3] = m;

@@ -1013,6 +1013,28 @@ extern "C" __global__ void __launch_bounds__(PTX_BLOCK) ptx_kat_trace_kernel_loo
 // ================================================================================================
 // Host side
 // ================================================================================================
+// ---- launch policy ----------------------------------------------------------------------------------------------------
+// What a ptx_trace* call runs is a function of the uploaded scene's class, the options, the launch's length and the
+// sequence of calls on the context -- of nothing else (not of host timing).  configure() evaluates that function once per
+// class of launch length and keeps the result as a table (ptx_ctx::policy: rows by ascending `upto`), together with the
+// one form every launch can fall back to, whole-pixel jobs (ptx_ctx::pixels_form: ptx_trace_n_static, radiance capture,
+// a host that waits for every frame).  launch_trace looks the row up; what depends on the frame's size (reservation
+// sizes, chunks, launches in flight within the staging memory) is worked out from the row there (resolve_launch).
+typedef void (*TraceKernel)(const TraceParams);
+enum : uint8_t { JOBS_PIXELS = 0, JOBS_SAMPLES = 1, JOBS_POOLS = 2 };
+struct LaunchForm {
+    uint8_t jobs = JOBS_PIXELS;   // whole pixels folded in the lane | single samples staged for ptx_fold_kernel | the same from sorted path pools
+    bool sched = false;           // the wave-scheduled family (else lockstep)
+    bool claim = false;           // the grid is the resident workgroups and lanes claim jobs (else one workgroup per 16x16 block)
+    TraceKernel kernel = nullptr;
+    uint32_t counters = 1;        // job counters the reservations are spread over (ptx_trace_kernel_lds_ranged: up to sixteen)
+    uint32_t guided_k = 0;        // reservations of 1/(k * waves) of the jobs left (0: fixed size)
+    uint32_t paced_m = 0;         // reservations sized to come m * waves * 10 ns apart (0: fixed size)
+    uint32_t pool_m = 0;          // JOBS_POOLS: paths per workgroup pool
+    uint32_t flights = 0;         // launches of sample jobs in flight at most; 0 = PTX_FLIGHTS_DEFAULT within the staging memory
+};
+struct PolicyRow { uint32_t upto; LaunchForm form; };  // launches of up to `upto` samples
+
 struct ptx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1044,6 +1066,10 @@ struct ptx_ctx {
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
     const char* last_kernel = nullptr;  // the trace kernel of the latest launch since the scene was uploaded
     std::string last_info;              // ... and what else the launch policy chose for it (ptx_last_launch_info)
+    std::string plan_info;              // ptx_launch_plan's answer
+    std::vector<PolicyRow> policy;      // the launch policy of the uploaded scene under the current options (configure())
+    LaunchForm pixels_form;             // ... and its whole-pixel form
+    bool drained = false;               // the host has synchronised with the context since its latest trace launch
     // ptx_set_option: explicit overrides of the per-scene choices (tests and measurement runs); the defaults mean "as measured"
     struct Options {
         int family = -1;          // kernel_family: -1 per scene, 0 lockstep, 1 wave-scheduled
@@ -1057,7 +1083,7 @@ struct ptx_ctx {
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
         int sorted_pool = -1;     // -1 per scene and launch, 0 / 1: lockstep LDS kernel over sorted path pools (sample jobs, long launches)
-        int idle_whole = 1;       // 1: a one-sample launch that finds the GPU idle runs whole-pixel jobs (no staging, no fold kernel); 0 never
+        int host_waits = -1;      // host_waits_per_frame: -1 by the call sequence, 0 one-sample launches always overlap, 1 they never do (launch_trace)
         int pool_over = -1;       // -1 per scene (4; lit meshes 0): launches of more samples than this may trace from pools
         uint32_t pool_paths = 0;  // 0 = 4096, else paths per workgroup pool (a power of two from 256 to 16384)
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
@@ -1105,8 +1131,7 @@ struct ptx_ctx {
     size_t xchg_floats = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    std::chrono::steady_clock::time_point last_launch{};  // when the latest trace launch was enqueued (host clock)
-    bool found_idle = false;                               // ... and whether it found the one before it finished
+    bool found_idle = false;       // the latest one-sample launch came after a synchronising call (launch_trace)
     std::vector<hipEvent_t> free_events;
     double acc_ms = 0.0;
     uint32_t acc_launches = 0;
@@ -1203,6 +1228,7 @@ int collect_timing(ptx_ctx* c) {
         c->free_events.push_back(pr.first);
         c->free_events.push_back(pr.second);
     }
+    if (!c->pending.empty()) c->drained = true;  // the latest launch's last event has completed
     c->pending.clear();
     return PTX_OK;
 }
@@ -1406,7 +1432,8 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
     else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
     else if (k == "sorted_pool") { if ((ok = in(-1, 1))) o.sorted_pool = (int)value; }
-    else if (k == "idle_whole") { if ((ok = in(0, 1))) o.idle_whole = (int)value; }
+    else if (k == "host_waits_per_frame") { if ((ok = in(-1, 1))) o.host_waits = (int)value; }
+    else if (k == "idle_whole") { if ((ok = in(0, 1))) o.host_waits = value ? -1 : 0; }  // the option's earlier name
     else if (k == "pool_over") { if ((ok = in(-1, 0x7FFFFFFF))) o.pool_over = (int)value; }
     else if (k == "pool_paths") { if ((ok = value == 0 || (value >= 256 && value <= 16384 && (value & (value - 1)) == 0))) o.pool_paths = (uint32_t)value; }
     else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
@@ -1433,7 +1460,6 @@ static bool pick_sched(const DScene& sc, uint32_t type_mask, int forced) {
     return (type_mask & (1u << FIG_MEBIUS)) != 0u;
 }
 
-typedef void (*TraceKernel)(const TraceParams);
 static const char* trace_kernel_label(TraceKernel k) {
 #define PTX_NAME(f) if (k == f) return #f;
     PTX_NAME(ptx_trace_kernel) PTX_NAME(ptx_trace_kernel_lds) PTX_NAME(ptx_trace_kernel_lds_ranged) PTX_NAME(ptx_trace_kernel_lds_sorted) PTX_NAME(ptx_trace_kernel_sorted) PTX_NAME(ptx_trace_kernel_frac)
@@ -1454,8 +1480,205 @@ static size_t trace_lds_bytes(const ptx_ctx* c) {
     return lds + c->sc.lds_scene_bytes + (c->sched && c->sc.has_fractals != 0u ? (size_t)PTX_WAVES_PER_BLOCK * 64u * SC_FRAC_FIELDS * 4u : 0u);
 }
 
-// Per-scene choices (kernel family, scheduling shares, claim size, resident workgroups per compute unit) from the
-// uploaded scene's class and the options; run at upload and whenever an option changes.
+
+// The form a launch of n samples takes on the uploaded scene under the current options.  samples_allowed false: the
+// whole-pixel form (what ptx_trace_n_static, radiance capture and a host that waits for every frame run), which does not
+// depend on n.  Every choice below was measured; frames are identical under all of them (tested).
+static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
+    const DScene& sc = c->sc;
+    const bool frac = sc.has_fractals != 0u, lds = sc.lds_scene_bytes > 0u;
+    LaunchForm f;
+    // Small scenes with a Moebius strip (staged in LDS, wave-scheduled by the per-scene rule): launches of more than four samples
+    // run the lockstep kernel over sorted path pools instead (all.yaml 25.1 -> 21.8 ms per 16 samples at 1080p, mebius.yaml
+    // 17.3 -> 14.6; lane-owned lockstep 27.5 / 15.8), shorter ones stay wave-scheduled.  Same LDS bytes, same occupancy.
+    // Shallow meshes with lights (unit_logo.yaml: six bounces and five occlusion queries per path) likewise: 72 -> 44 ms per 16
+    // samples at 1080p; without lights (a bounce or two into the sky) the wave-scheduled kernels are up to twice as fast as pools.
+    const bool lit_mesh = c->plain_mesh && sc.nlight > 0u;
+    // Launches of more samples than this may trace from pools.  Pools do not overlap with the next launch (one set per context),
+    // lane-owned launches of up to four samples do: back to back the Cornell box loses 10-50 % at one sample per launch from
+    // pools, gains 8 % at four, rings.yaml loses 23 % at four (in turn pools win from two samples up).  A lit mesh's paths
+    // are long enough for pools to win at every length (unit_logo.yaml, one / four samples per launch: 430 -> 610 / 471 -> 750 Mpaths/s).
+    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : (lit_mesh ? 0u : 4u);
+    // Sample jobs + fold against whole-pixel jobs: configure().  (Sample jobs need a claiming grid: below.)
+    const bool can_split = samples_allowed && c->split && n <= c->split_upto;
+    const bool pools_instead = c->opt.family < 0 && c->opt.sorted_pool != 0 && (lds || lit_mesh) && !frac && n > pool_over && can_split;
+    f.sched = c->sched && !pools_instead;
+    // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
+    // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
+    // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.  The pools' grid is the resident
+    // workgroups too -- but only a launch that does trace from pools may be given that grid: the lockstep kernel for scenes in
+    // global memory does not claim, it runs one workgroup per 16x16 block.
+    const bool pools_global = c->opt.sorted_pool == 1 || (c->opt.sorted_pool != 0 && lit_mesh && !f.sched);
+    f.claim = f.sched || (PTX_CLAIM_LDS && lds) || (pools_global && !frac && n > pool_over && can_split);
+    const bool split = f.claim && can_split;
+    // Long launches of sample jobs on the lockstep kernels trace from sorted path pools (sorted_body); short ones, whose
+    // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
+    const bool sorted = split && !f.sched && !frac && n > pool_over && (lds ? c->opt.sorted_pool != 0 : pools_global);
+    f.jobs = sorted ? JOBS_POOLS : (split ? JOBS_SAMPLES : JOBS_PIXELS);
+    f.kernel = f.sched == c->sched ? trace_kernel_of(c) : (lds ? ptx_trace_kernel_lds : ptx_trace_kernel);
+    if (split && f.sched && !frac) f.kernel = lds ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
+    if (sorted) {
+        f.kernel = lds ? ptx_trace_kernel_lds_sorted : ptx_trace_kernel_sorted;  // same LDS, four waves per SIMD
+        // measured on the Cornell box, Gpath-bounce/s at 16 / 128 samples per launch: 1024 paths 11.6 / 12.3, 2048 12.2 / 13.2,
+        // 4096 12.5 / 13.6, 8192 12.0 / 13.8, 16384 11.0 / 13.9 (a longer launch amortises a larger pool's first and last rounds)
+        f.pool_m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : 2048u));
+    }
+    // Deep trees: a wave's reservations start large and shrink with the jobs left, so its lanes stay on neighbouring pixels for
+    // longer while the launch still ends evenly (all.yaml + 10 M triangles, 8 samples per launch: 36.6 -> 36.2 ms; shallow meshes,
+    // whose pixels differ a hundredfold in cost, lose up to half with reservations of thousands of jobs).
+    f.guided_k = !f.sched || frac ? 0u : (c->opt.claim_guided >= 0 ? (uint32_t)c->opt.claim_guided : (sc.stack_entries >= PT_DEEP_TREE ? 8u : 0u));
+    // The lockstep kernels with the scene in LDS, lane-owned paths (launches of up to four samples): half of the reference's
+    // scenes finish a path in less time than its share of a 64-job reservation takes at the counter (4.5 G paths/s whatever the
+    // scene).  There a wave paces itself: reservations used up in under 2/3 of 4 * waves * 10 ns double (up to 512 jobs), never
+    // beyond 1/(8 * waves) of the jobs left.  1080p, G paths/s at 4 samples per launch, in turn / back to back: test.yaml 4.1 / 6.2
+    // -> 5.4 / 8.1, aelita.yaml 4.1 / 6.4 -> 4.8 / 7.4, earth.yaml 4.0 / 5.6 -> 4.3 / 5.9, Cornell box and rings.yaml unchanged.
+    // A looser cap (1/(2 * waves)) reaches 9.2 / 16.3 on test.yaml and halves rings.yaml, whose pixels differ most in cost.
+    f.paced_m = f.sched || frac ? 0u : (c->opt.claim_paced >= 0 ? (uint32_t)c->opt.claim_paced : (lds ? 4u : 0u));
+    // One counter hands out jobs in frame order: all waves of the GPU work on the same few rows at a time, which a deep tree in
+    // memory wants (every wave walks the same part of it).  Scenes whose paths cost little want reservations served faster than one
+    // address can (88 M a second): sixteen counters, each handing out a sixteenth of the jobs, a wave moving on when its counter runs out.
+    // Only the lockstep kernel has the registers for it, in a variant of its own (CLAIM_RANGED, sched_dev.h: its counters count
+    // from zero, the others' one counter from the first unassigned job), and only scenes without lights run it: their paths end
+    // at the sky after a bounce or two, and the hand-out is what bounds them (test.yaml, planet.yaml: 1.5 to 2.5 times the rate at
+    // every frame size, in turn and back to back).  Scenes with lights (three bounces per path and more) gain up to a quarter at
+    // 1080p in turn and lose 5-12 % at 4K and back to back: the variant's code is a few per cent slower than the plain kernel's.
+    const uint32_t counters_wanted = f.sched || frac || !lds ? 1u : (c->opt.claim_ranges ? c->opt.claim_ranges : (sc.nlight == 0u ? (uint32_t)PTX_CLAIM_RANGES : 1u));
+    if (f.kernel == ptx_trace_kernel_lds && counters_wanted > 1u) {
+        f.kernel = ptx_trace_kernel_lds_ranged;  // same LDS, same occupancy
+        f.counters = counters_wanted;
+    }
+    // Overlap hides a launch's last paths behind the next launch: a quarter of a one-sample launch of the Cornell box, but
+    // 0.4 % of a 128-sample one (0.7 % of 8 samples of the 10 M-triangle scene); fractal launches end on tens of milliseconds
+    // of a few lanes marching whatever their length (1.9 % of 128 samples).  Longer launches of the other scenes run in turn,
+    // which also keeps every kernel's duration a quantity of its own.  One set of pools per context: pools run in turn.
+    f.flights = sorted ? 1u : (c->opt.flights >= 1u ? c->opt.flights : (!frac && n > 4u ? 1u : 0u));
+    return f;
+}
+
+// The table: one row per class of launch length.  The thresholds are those form_for() compares n with.
+static void build_policy(ptx_ctx* c) {
+    const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
+    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : (lit_mesh ? 0u : 4u);
+    std::vector<uint32_t> upto = {1u, 2u, 4u, 16u, 63u, pool_over, c->split_upto, 0xFFFFFFFFu};
+    std::sort(upto.begin(), upto.end());
+    upto.erase(std::unique(upto.begin(), upto.end()), upto.end());
+    c->policy.clear();
+    for (uint32_t u : upto) {
+        if (u == 0u) continue;
+        PolicyRow r;
+        r.upto = u;
+        r.form = form_for(c, u, true);
+        c->policy.push_back(r);
+    }
+    c->pixels_form = form_for(c, 1u, false);
+}
+
+// Jobs a wave reserves per device atomic (claim_jobs): 1 = just what its lanes need at that moment.  m: samples of the
+// launch (JOBS_PIXELS) or of its chunk.
+static uint32_t reservation_jobs(const ptx_ctx* c, const LaunchForm& f, uint32_t m, uint32_t n_blocks) {
+    if (c->opt.claim_tile) return c->opt.claim_tile;
+    const bool frac = c->sc.has_fractals != 0u;
+    if (f.jobs == JOBS_PIXELS) {
+        uint32_t t = c->claim_tile;
+        // Lockstep kernels: short launches are bound by the rate of the claims (one device atomic per finished pixel and wave),
+        // long ones lose 4 % when a wave's lanes sit on neighbouring pixels (Cornell box, 1080p: 1.3 ms against 2.0 at one sample
+        // per launch, 15.6 against 17.1 at 16, 30.1 against 29.1 at 32).
+        if (!f.sched && !frac && m <= 16u) t = 64u;
+        // Scheduled kernels on frames of 4 M pixels and more, one or two samples per launch: even one claim per 64 pixels is
+        // 130 k atomics on one address (teapot 4K, one sample per launch: 2.1 ms, 1.7 ms with 128 pixels per claim; longer
+        // launches and smaller frames are 3-6 % faster with 64).
+        if (f.sched && !frac && m <= 2u && n_blocks >= 16384u) t = 128u;
+        return t;
+    }
+    uint32_t t = !frac ? (n_blocks >= 16384u ? 128u : 64u) : (m >= 64u ? 256u : 128u);
+    // Shallow meshes finish 8 G paths a second and more: 64 jobs per reservation is more reservations than the counter serves
+    // (one device atomic on one address: about 10 ns), while a wave that reserves 512 jobs at the end of a short launch keeps
+    // the launch waiting.  About 49 k reservations per launch, 64 to 512 jobs each -- measured at 1080p, ms per launch of
+    // 1 / 2 / 4 / 8 / 16 / 64 samples with 64 jobs: 0.9 / 1.3 / 2.3 / 3.6 / 7.0 / 27.6, 128: 0.9 / 1.0 / 1.8 / 2.7 / 5.2 / 19.5,
+    // 256: 1.2 / 1.3 / 1.8 / 2.3 / 4.3 / 16.1, 512: 1.6 / 1.9 / 2.3 / 2.7 / 4.0 / 14.8 (teapot.yaml; iron_man.yaml and car.yaml alike).
+    if (c->plain_mesh && f.sched) {
+        const uint32_t per = (n_blocks * 256u * m / 49152u + 63u) & ~63u;
+        t = per < 64u ? 64u : (per > 512u ? 512u : per);
+    }
+    return t;
+}
+
+// Everything launch_trace decides before it touches a buffer.
+struct LaunchChoice {
+    LaunchForm f;
+    bool alone = false;            // a one-sample launch of a host that waits for every frame
+    uint32_t chunk = 0, depth = 1;  // samples per kernel launch; launches of sample jobs in flight
+    uint32_t tile0 = 0;            // jobs per reservation (of the first chunk)
+    uint32_t lds_stack = 0;        // traversal-stack entries per lane in LDS
+};
+// fixed: ptx_trace_n_static.  peek: ptx_launch_plan -- the context's record of the call sequence is read, not updated.
+static LaunchChoice resolve_launch(ptx_ctx* c, uint32_t n, bool fixed, uint32_t n_blocks, bool peek) {
+    LaunchChoice L;
+    const bool frac = c->sc.has_fractals != 0u;
+    const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
+    // One sample per launch with the GPU idle -- a host that reads every frame back before it asks for the next, as the
+    // reference's own frame loop presents every frame -- has no neighbour to overlap with: there the pixel folds its sample in
+    // the lane and no fold kernel follows (1080p, in turn: Cornell box 1.42 -> 1.24 ms, cube.yaml 0.67 -> 0.59, test.yaml
+    // 0.43 -> 0.31, teapot 0.85 -> 0.76; deep trees and the Moebius scenes lose 1-4 % and keep sample jobs).  Which host this
+    // is follows from the calls it makes, not from a clock: a launch is alone when the host has synchronised with the
+    // context (ptx_sync, a ptx_read_*, ptx_kernel_time*) since the launch before it, and did so before that one as well --
+    // the first launch after a read-back may be the head of a back-to-back burst, whose second launch should start beside
+    // it.  The host_waits_per_frame option states it outright: 1 every one-sample launch is alone, 0 none is.
+    const bool eligible = n == 1u && !fixed && !frac && (!c->sched || (c->plain_mesh && !lit_mesh));
+    if (eligible && c->opt.host_waits != 0) {
+        const bool idle = c->drained;
+        L.alone = c->opt.host_waits == 1 || (idle && c->found_idle);
+        if (!peek) c->found_idle = idle;
+    } else if (!peek) {
+        c->found_idle = false;
+    }
+    if (!peek) c->drained = false;
+    const PolicyRow* row = &c->policy.back();
+    for (const PolicyRow& r : c->policy)
+        if (n <= r.upto) { row = &r; break; }
+    // whole-pixel jobs: the static entry point (no staging buffer), radiance capture (its sample index is launch-relative), a launch alone
+    L.f = fixed || c->dbg || L.alone ? c->pixels_form : row->form;
+    if (fixed && L.f.kernel == ptx_trace_kernel_lds_ranged) { L.f.kernel = ptx_trace_kernel_lds; L.f.counters = 1u; }  // its scratch array holds one counter
+    L.chunk = n;
+    L.depth = 1u;
+    L.lds_stack = c->sc.lds_stack_entries;
+    if (L.f.jobs != JOBS_PIXELS) {
+        // Sample jobs are staged in chunks that bound the staging buffer (4 GiB of the 288: 128 samples of a 1080p frame) and the
+        // job count; every chunk traces on a stream of its own (a "flight") into a staging buffer of its own, beside the tails of
+        // the chunks and calls before it, and only the folds follow one another, on the context's stream.
+        const size_t frame_pixels = (size_t)c->w * c->h;
+        const size_t by_mem = ((size_t)4 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)n_blocks * 256u);
+        size_t m = by_mem < by_jobs ? by_mem : by_jobs;
+        if (c->opt.split_chunk >= 1u && c->opt.split_chunk < m) m = c->opt.split_chunk;
+        if (m < 1) m = 1;
+        if (m < L.chunk) L.chunk = (uint32_t)m;
+        const size_t in_flight = ((size_t)8 << 30) / (L.chunk * frame_pixels * sizeof(float4));
+        const uint32_t by_staging = in_flight < 2 ? 2u : (uint32_t)in_flight;
+        // measured, fractals 1080p, one sample per launch, ms per frame with 1 / 2 / 4 / 6 / 8 in flight: 58 / 28.5 / 29 / 20.6 / 21.9
+        // (HIP's default of four hardware queues per process; with GPU_MAX_HW_QUEUES=8 in the host's environment: 58 / 27.5 / 17.4 / 14.1 / 16.8)
+        if (L.f.flights == 0u) L.depth = in_flight >= PTX_FLIGHTS_DEFAULT ? PTX_FLIGHTS_DEFAULT : by_staging;
+        else L.depth = L.f.flights < in_flight || L.f.flights <= 2u ? L.f.flights : by_staging;
+        // the slots of the running mean, which sample jobs of the wave-scheduled kernels do not keep, hold two more stack entries (same LDS bytes: sched_body)
+        if (L.f.sched && !frac && c->sc.lds_scene_bytes == 0u && c->sc.stack_entries > PT_LDS_STACK) {
+            const uint32_t more = PT_LDS_STACK + SC_SAMPLE_JOB_FREE / 2u;
+            L.lds_stack = c->sc.stack_entries < more ? c->sc.stack_entries : more;
+        }
+    }
+    L.tile0 = L.f.claim ? reservation_jobs(c, L.f, n < L.chunk ? n : L.chunk, n_blocks) : 0u;
+    return L;
+}
+static std::string describe_launch(const LaunchChoice& L) {
+    char buf[256];
+    const LaunchForm& f = L.f;
+    snprintf(buf, sizeof(buf), "%s jobs=%s claim_tile=%u counters=%u guided=%u paced=%u pool=%u flights=%u chunk=%u lds_stack=%u",
+             trace_kernel_label(f.kernel), f.jobs == JOBS_POOLS ? "pools" : (f.jobs == JOBS_SAMPLES ? "samples" : "pixels"), L.tile0,
+             f.claim ? f.counters : 0u, f.claim && L.tile0 > 1u ? f.guided_k : 0u, f.claim && L.tile0 > 1u ? f.paced_m : 0u, f.pool_m,
+             f.jobs != JOBS_PIXELS ? L.depth : 0u, L.chunk, L.lds_stack);
+    return buf;
+}
+
+// Per-scene choices (kernel family, scheduling shares, claim size, the launch policy's table, resident workgroups per compute
+// unit) from the uploaded scene's class and the options; run at upload and whenever an option changes.
 static int configure(ptx_ctx* c) {
     if (!c->have_scene) return PTX_OK;
     const DScene& sc = c->sc;
@@ -1487,6 +1710,7 @@ static int configure(ptx_ctx* c) {
     if (c->opt.split_upto >= 0 && !(c->sched && sc.has_fractals)) c->split_upto = (uint32_t)c->opt.split_upto;
     c->claim_tile = c->sched && !sc.has_fractals ? 64u : 1u;  // measured: see claim_pixel
     if (c->opt.claim_tile) c->claim_tile = c->opt.claim_tile;
+    build_policy(c);
     // Resident workgroups per compute unit of the kernel this scene runs: the claiming kernels' grid.
     const TraceKernel kernel = trace_kernel_of(c);
     const size_t lds_all = trace_lds_bytes(c);
@@ -1782,25 +2006,10 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     P.stats = c->stats;
     const bool frac = c->sc.has_fractals != 0u;
     const size_t lds_all = trace_lds_bytes(c);
-    // Small scenes with a Moebius strip (staged in LDS, wave-scheduled by the per-scene rule): launches of more than four samples
-    // run the lockstep kernel over sorted path pools instead (all.yaml 25.1 -> 21.8 ms per 16 samples at 1080p, mebius.yaml
-    // 17.3 -> 14.6; lane-owned lockstep 27.5 / 15.8), shorter ones stay wave-scheduled.  Same LDS bytes, same occupancy.
-    // Shallow meshes with lights (unit_logo.yaml: six bounces and five occlusion queries per path) likewise: 72 -> 44 ms per 16
-    // samples at 1080p; without lights (a bounce or two into the sky) the wave-scheduled kernels are up to twice as fast as pools.
-    const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
-    // Launches of more samples than this may trace from pools.  Pools do not overlap with the next launch (one set per context),
-    // lane-owned launches of up to four samples do: back to back the Cornell box loses 10-50 % at one sample per launch from
-    // pools, gains 8 % at four, rings.yaml loses 23 % at four (in turn pools win from two samples up).  A lit mesh's paths
-    // are long enough for pools to win at every length (unit_logo.yaml, one / four samples per launch: 430 -> 610 / 471 -> 750 Mpaths/s).
-    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : (lit_mesh ? 0u : 4u);
-    const bool sched = c->sched && !(c->opt.family < 0 && c->opt.sorted_pool != 0 && (c->sc.lds_scene_bytes > 0u || lit_mesh) && !frac && n > pool_over && !fixed &&
-                                     c->split && !c->dbg && n <= c->split_upto);
-    TraceKernel kernel = sched == c->sched ? trace_kernel_of(c) : (c->sc.lds_scene_bytes > 0u ? ptx_trace_kernel_lds : ptx_trace_kernel);
-    // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
-    // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
-    // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.
-    const bool pools_global = c->opt.sorted_pool == 1 || (c->opt.sorted_pool != 0 && lit_mesh && !sched);
-    const bool claim = sched || (PTX_CLAIM_LDS && c->sc.lds_scene_bytes > 0u) || (pools_global && !frac && n > pool_over);  // the pools' grid is the resident workgroups too
+    const LaunchChoice L = resolve_launch(c, n, fixed, P.n_blocks, false);
+    const LaunchForm& form = L.f;
+    const TraceKernel kernel = form.kernel;
+    const bool claim = form.claim, split = form.jobs != JOBS_PIXELS, sorted = form.jobs == JOBS_POOLS;
     uint32_t grid = P.n_blocks;
     if (claim) {
         int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
@@ -1831,28 +2040,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         }
         P.wave_state = c->wave_state;
     }
-    // Deep trees: a wave's reservations start large and shrink with the jobs left, so its lanes stay on neighbouring pixels for
-    // longer while the launch still ends evenly (all.yaml + 10 M triangles, 8 samples per launch: 36.6 -> 36.2 ms; shallow meshes,
-    // whose pixels differ a hundredfold in cost, lose up to half with reservations of thousands of jobs).
-    const uint32_t guided_k = !sched || frac ? 0u : (c->opt.claim_guided >= 0 ? (uint32_t)c->opt.claim_guided : (c->sc.stack_entries >= PT_DEEP_TREE ? 8u : 0u));
-    // The lockstep kernels with the scene in LDS, lane-owned paths (launches of up to four samples): half of the reference's
-    // scenes finish a path in less time than its share of a 64-job reservation takes at the counter (4.5 G paths/s whatever the
-    // scene).  There a wave paces itself: reservations used up in under 2/3 of 4 * waves * 10 ns double (up to 512 jobs), never
-    // beyond 1/(8 * waves) of the jobs left.  1080p, G paths/s at 4 samples per launch, in turn / back to back: test.yaml 4.1 / 6.2
-    // -> 5.4 / 8.1, aelita.yaml 4.1 / 6.4 -> 4.8 / 7.4, earth.yaml 4.0 / 5.6 -> 4.3 / 5.9, Cornell box and rings.yaml unchanged.
-    // A looser cap (1/(2 * waves)) reaches 9.2 / 16.3 on test.yaml and halves rings.yaml, whose pixels differ most in cost.
-    const uint32_t paced_m = sched || frac ? 0u : (c->opt.claim_paced >= 0 ? (uint32_t)c->opt.claim_paced : (c->sc.lds_scene_bytes > 0u ? 4u : 0u));
     const uint32_t paced_cap = c->opt.claim_cap >= 0 ? (uint32_t)c->opt.claim_cap : 8u;
-    // One counter hands out jobs in frame order: all waves of the GPU work on the same few rows at a time, which a deep tree in
-    // memory wants (every wave walks the same part of it).  Scenes whose paths cost little want reservations served faster than one
-    // address can (88 M a second): sixteen counters, each handing out a sixteenth of the jobs, a wave moving on when its counter runs out.
-    // Only the lockstep kernel has the registers for it, in a variant of its own (CLAIM_RANGED, sched_dev.h: its counters count
-    // from zero, the others' one counter from the first unassigned job), and only scenes without lights run it: their paths end
-    // at the sky after a bounce or two, and the hand-out is what bounds them (test.yaml, planet.yaml: 1.5 to 2.5 times the rate at
-    // every frame size, in turn and back to back).  Scenes with lights (three bounces per path and more) gain up to a quarter at
-    // 1080p in turn and lose 5-12 % at 4K and back to back: the variant's code is a few per cent slower than the plain kernel's.
-    const uint32_t ranges_wanted = sched || frac || fixed || c->sc.lds_scene_bytes == 0u ? 1u
-                                   : (c->opt.claim_ranges ? c->opt.claim_ranges : (c->sc.nlight == 0u ? (uint32_t)PTX_CLAIM_RANGES : 1u));
     if (claim) {
         if (!fixed && !c->flight_counters) {
             HIP_TRY(c, hipMalloc((void**)&c->flight_counters, (PTX_FLIGHTS + 1) * (PTX_CLAIM_RANGES + 1) * 256));
@@ -1860,74 +2048,18 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         }
         P.job_counter = fixed ? (uint32_t*)c->static_scratch : c->flight_counters + PTX_FLIGHTS * (PTX_CLAIM_RANGES + 1) * 64;
         P.total_jobs = P.n_blocks * 256u;
-        P.claim_tile = c->claim_tile;
-        // Lockstep kernels: short launches are bound by the rate of the claims (one device atomic per finished pixel and wave),
-        // long ones lose 4 % when a wave's lanes sit on neighbouring pixels (Cornell box, 1080p: 1.3 ms against 2.0 at one sample
-        // per launch, 15.6 against 17.1 at 16, 30.1 against 29.1 at 32).
-        if (!c->opt.claim_tile && !sched && !frac && n <= 16u) P.claim_tile = 64u;
-        // Scheduled kernels on frames of 4 M pixels and more, one or two samples per launch: even one claim per 64 pixels is
-        // 130 k atomics on one address (teapot 4K, one sample per launch: 2.1 ms, 1.7 ms with 128 pixels per claim; longer
-        // launches and smaller frames are 3-6 % faster with 64).
-        if (!c->opt.claim_tile && sched && !frac && n <= 2u && P.n_blocks >= 16384u) P.claim_tile = 128u;
-        P.claim_shift = guided_k && P.claim_tile > 1u ? log2_ceil(guided_k * waves) : 0u;
-        P.claim_period = paced_m && P.claim_tile > 1u ? paced_m * (uint32_t)waves : 0u;
+        P.claim_tile = L.tile0;
+        P.claim_shift = form.guided_k && P.claim_tile > 1u ? log2_ceil(form.guided_k * waves) : 0u;
+        P.claim_period = form.paced_m && P.claim_tile > 1u ? form.paced_m * (uint32_t)waves : 0u;
         P.claim_cap_shift = paced_cap ? log2_ceil(paced_cap * waves) + 6u : 0u;
         P.share_walk = c->shares[0]; P.share_post = c->shares[1]; P.share_march = c->shares[2];
         P.walk_single = c->sc.stack_entries >= PT_DEEP_TREE ? 1u : 0u;
         if (c->opt.walk_mode >= 0) P.walk_single = (uint32_t)c->opt.walk_mode;
         P.share_leaf = c->share_leaf;
     }
-    // Fractal scenes: a pixel on a fractal's silhouette costs hundreds of times a background pixel, and with one
-    // lane folding all n samples of its pixel the launch ends on a few lanes finishing theirs.  There the jobs
-    // are single samples, staged and folded in order by ptx_fold_kernel, in chunks that bound the staging buffer
-    // (4 GiB of the 288: 128 samples of a 1080p frame) and the job count.  Radiance capture keeps whole-pixel jobs
-    // (its sample index is launch-relative).
-    // Such a launch still ends on its longest paths (tens of milliseconds of a few lanes marching), and it reads nothing
-    // an earlier launch writes: so every chunk traces on a stream of its own (a "flight") into a staging buffer of its own,
-    // beside the tails of the chunks and calls before it, and only the folds follow one another, on the context's stream.
-    // Which scenes and launch sizes use this form is measured per scene class (configure()): all but long launches of shallow
-    // meshes without marched figures.  Staging costs 16 bytes per sample, written once and read once: 4.2 GB per 128-sample
-    // launch of a 1080p frame, two such buffers in flight.
-    // One sample per launch with the GPU idle -- a host that reads every frame back before it asks for the next, as the
-    // reference's own frame loop presents every frame -- has no neighbour to overlap with: there the pixel folds its sample in
-    // the lane and no fold kernel follows (1080p, in turn: Cornell box 1.42 -> 1.24 ms, cube.yaml 0.67 -> 0.59, test.yaml
-    // 0.43 -> 0.31, teapot 0.85 -> 0.76; deep trees and the Moebius scenes lose 1-4 % and keep sample jobs).  A launch that
-    // finds the previous one still running is in a back-to-back sequence and overlaps with it as sample jobs.
-    // (The event is asked only when the previous launch was enqueued more than 0.2 ms ago: a host that enqueues launch after
-    // launch never asks -- the query cost the Cornell box 1-4 % back to back.)
-    bool alone = false;
-    const auto now = std::chrono::steady_clock::now();
-    if (n == 1u && !fixed && !frac && c->opt.idle_whole != 0 && (!c->sched || (c->plain_mesh && !lit_mesh)) &&
-        std::chrono::duration<double, std::micro>(now - c->last_launch).count() > 200.0) {
-        // twice in a row: the first launch of a back-to-back burst finds the GPU idle too, and a whole-pixel launch at its head
-        // would keep the second from starting beside it
-        bool idle = c->pending.empty();
-        if (!idle) {
-            idle = hipEventQuery(c->pending.back().second) == hipSuccess;
-            (void)hipGetLastError();  // "not ready" is an answer, not an error: it must not be what the launch below reports
-        }
-        alone = idle && c->found_idle;
-        c->found_idle = idle;
-    } else {
-        c->found_idle = false;
-    }
-    c->last_launch = now;
-    const bool split = !fixed && claim && c->split && !c->dbg && n <= c->split_upto && !alone;
-    if (split && sched && !frac) {
-        kernel = c->sc.lds_scene_bytes > 0u ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
-        // the slots of the running mean, which sample jobs do not keep, hold two more stack entries (same LDS bytes: sched_body)
-        if (c->sc.lds_scene_bytes == 0u && c->sc.stack_entries > PT_LDS_STACK) {
-            const uint32_t more = PT_LDS_STACK + SC_SAMPLE_JOB_FREE / 2u;
-            P.sc.lds_stack_entries = c->sc.stack_entries < more ? c->sc.stack_entries : more;
-        }
-    }
-    // Long launches of sample jobs on the lockstep LDS kernels trace from sorted path pools (sorted_body); short ones, whose
-    // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !sched && !frac && n > pool_over && (c->sc.lds_scene_bytes > 0u ? c->opt.sorted_pool != 0 : pools_global);
+    P.sc.lds_stack_entries = L.lds_stack;
     if (sorted) {
-        // measured on the Cornell box, Gpath-bounce/s at 16 / 128 samples per launch: 1024 paths 11.6 / 12.3, 2048 12.2 / 13.2,
-        // 4096 12.5 / 13.6, 8192 12.0 / 13.8, 16384 11.0 / 13.9 (a longer launch amortises a larger pool's first and last rounds)
-        const uint32_t m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : 2048u));
+        const uint32_t m = form.pool_m;
         if ((size_t)grid > c->pool_wgs || m > c->pool_m) {  // the buffers only grow: a smaller pool uses a part of each workgroup's share
             const size_t wgs = (size_t)grid > c->pool_wgs ? (size_t)grid : c->pool_wgs;
             const uint32_t cap = m > c->pool_m ? m : c->pool_m;
@@ -1942,57 +2074,18 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             c->pool_wgs = wgs; c->pool_m = cap;
         }
         P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;
-        kernel = c->sc.lds_scene_bytes > 0u ? ptx_trace_kernel_lds_sorted : ptx_trace_kernel_sorted;  // same LDS, four waves per SIMD
     }
-    const bool zero_based = kernel == ptx_trace_kernel_lds && ranges_wanted > 1u;
-    const uint32_t ranges = zero_based ? ranges_wanted : 1u;
-    if (zero_based) kernel = ptx_trace_kernel_lds_ranged;  // same LDS, same occupancy
+    const bool zero_based = kernel == ptx_trace_kernel_lds_ranged;
+    const uint32_t ranges = form.counters;
     c->last_kernel = trace_kernel_label(kernel);
-    const uint32_t whole_claim_tile = P.claim_tile;
-    uint32_t chunk = n;
-    size_t frame_pixels = 0;
-    uint32_t depth = 1;
+    c->last_info = describe_launch(L) + "; grid=" + std::to_string(grid);
+    const uint32_t chunk = L.chunk, depth = L.depth;
+    const size_t frame_pixels = (size_t)c->w * c->h;
     if (split) {
-        frame_pixels = (size_t)c->w * c->h;
-        size_t by_mem = ((size_t)4 << 30) / (frame_pixels * sizeof(float4)), by_jobs = 0x7FFFFFFFu / ((size_t)P.n_blocks * 256u);
-        size_t m = by_mem < by_jobs ? by_mem : by_jobs;
-        if (c->opt.split_chunk >= 1u && c->opt.split_chunk < m) m = c->opt.split_chunk;
-        if (m < 1) m = 1;
-        if (m < chunk) chunk = (uint32_t)m;
         P.frame_pixels = (uint32_t)frame_pixels;
-        const size_t in_flight = ((size_t)8 << 30) / (chunk * frame_pixels * sizeof(float4));
-        // measured, fractals 1080p, one sample per launch, ms per frame with 1 / 2 / 4 / 6 / 8 in flight: 58 / 28.5 / 29 / 20.6 / 21.9
-        // (HIP's default of four hardware queues per process; with GPU_MAX_HW_QUEUES=8 in the host's environment: 58 / 27.5 / 17.4 / 14.1 / 16.8)
-        depth = in_flight >= PTX_FLIGHTS_DEFAULT ? PTX_FLIGHTS_DEFAULT : (in_flight < 2 ? 2u : (uint32_t)in_flight);
-        // Overlap hides a launch's last paths behind the next launch: a quarter of a one-sample launch of the Cornell box, but
-        // 0.4 % of a 128-sample one (0.7 % of 8 samples of the 10 M-triangle scene); fractal launches end on tens of milliseconds
-        // of a few lanes marching whatever their length (1.9 % of 128 samples).  Longer launches of the other scenes run in turn,
-        // which also keeps every kernel's duration a quantity of its own.
-        if (!frac && n > 4u) depth = 1u;
-        if (c->opt.flights >= 1u) depth =c->opt.flights < in_flight || c->opt.flights <= 2u ? c->opt.flights : (in_flight < 2 ? 2u : (uint32_t)in_flight);
-        if (sorted) depth = 1u;  // one set of pools per context
         if (!c->barrier) HIP_TRY(c, hipEventCreateWithFlags(&c->barrier, hipEventDisableTiming));
     } else {
         c->order_dirty = true;
-    }
-    {
-        // what was chosen, for profiles, bench lines and the policy tests (ptx_last_launch_info); the part before ';' does not
-        // depend on the device's size
-        uint32_t tile0 = whole_claim_tile;
-        if (split && !c->opt.claim_tile) {
-            const uint32_t m0 = n < chunk ? n : chunk;
-            tile0 = !frac ? (P.n_blocks >= 16384u ? 128u : 64u) : (m0 >= 64u ? 256u : 128u);
-            if (c->plain_mesh && sched) {
-                const uint32_t per = (P.n_blocks * 256u * m0 / 49152u + 63u) & ~63u;
-                tile0 = per < 64u ? 64u : (per > 512u ? 512u : per);
-            }
-        }
-        char buf[256];
-        snprintf(buf, sizeof(buf), "%s jobs=%s claim_tile=%u counters=%u guided=%u paced=%u pool=%u flights=%u chunk=%u lds_stack=%u; grid=%u",
-                 c->last_kernel, sorted ? "pools" : (split ? "samples" : "pixels"), claim ? tile0 : 0u, claim ? ranges : 0u,
-                 claim && tile0 > 1u ? guided_k : 0u, claim && tile0 > 1u ? paced_m : 0u, sorted ? P.pool_m : 0u, split ? depth : 0u, chunk,
-                 P.sc.lds_stack_entries, grid);
-        c->last_info = buf;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!fixed) {
@@ -2016,18 +2109,9 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             continue;
         }
         P.split_n = m; P.total_jobs = P.n_blocks * 256u * m;
-        if (!c->opt.claim_tile) P.claim_tile = !frac ? (P.n_blocks >= 16384u ? 128u : 64u) : (m >= 64u ? 256u : 128u);
-        // Shallow meshes finish 8 G paths a second and more: 64 jobs per reservation is more reservations than the counter serves
-        // (one device atomic on one address: about 10 ns), while a wave that reserves 512 jobs at the end of a short launch keeps
-        // the launch waiting.  About 49 k reservations per launch, 64 to 512 jobs each -- measured at 1080p, ms per launch of
-        // 1 / 2 / 4 / 8 / 16 / 64 samples with 64 jobs: 0.9 / 1.3 / 2.3 / 3.6 / 7.0 / 27.6, 128: 0.9 / 1.0 / 1.8 / 2.7 / 5.2 / 19.5,
-        // 256: 1.2 / 1.3 / 1.8 / 2.3 / 4.3 / 16.1, 512: 1.6 / 1.9 / 2.3 / 2.7 / 4.0 / 14.8 (teapot.yaml; iron_man.yaml and car.yaml alike).
-        if (!c->opt.claim_tile && c->plain_mesh && sched) {
-            const uint32_t per = (P.total_jobs / 49152u + 63u) & ~63u;
-            P.claim_tile = per < 64u ? 64u : (per > 512u ? 512u : per);
-        }
-        P.claim_shift = guided_k && P.claim_tile > 1u ? log2_ceil(guided_k * waves) : 0u;
-        P.claim_period = paced_m && P.claim_tile > 1u ? paced_m * (uint32_t)waves : 0u;
+        P.claim_tile = reservation_jobs(c, form, m, P.n_blocks);
+        P.claim_shift = form.guided_k && P.claim_tile > 1u ? log2_ceil(form.guided_k * waves) : 0u;
+        P.claim_period = form.paced_m && P.claim_tile > 1u ? form.paced_m * (uint32_t)waves : 0u;
         ptx_ctx::Flight& f = c->flights[c->flight_seq % depth];
         const uint32_t slot = (uint32_t)(&f - c->flights);
         if (!f.stream) {
@@ -2103,6 +2187,7 @@ int ptx_sync(ptx_ctx* c) {
     if (!c) return PTX_ERR_BAD_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->drained = true;
     return PTX_OK;
 }
 
@@ -2112,6 +2197,7 @@ static int read_back(ptx_ctx* c, void* dst, const void* src, size_t bytes, const
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->drained = true;
     return PTX_OK;
 }
 int ptx_read_accum(ptx_ctx* c, float* o) { return read_back(c, o, c ? c->accum : nullptr, c ? (size_t)c->w * c->h * 16 : 0, "ptx_read_accum"); }
@@ -2601,6 +2687,14 @@ const char* ptx_trace_kernel_name(const ptx_ctx* c) {
 }
 
 const char* ptx_last_launch_info(const ptx_ctx* c) { return c ? c->last_info.c_str() : ""; }
+
+const char* ptx_launch_plan(ptx_ctx* c, uint32_t n) {
+    if (!c || !c->have_scene || !c->accum || n == 0u) return "";
+    const uint32_t total_blocks = ((c->tw + 15u) / 16u) * ((c->th + 15u) / 16u);
+    const uint32_t n_blocks = total_blocks > c->part_rank ? (total_blocks - c->part_rank + c->part_world - 1u) / c->part_world : 0u;
+    c->plan_info = describe_launch(resolve_launch(c, n, false, n_blocks, true));
+    return c->plan_info.c_str();
+}
 
 int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
     if (!c || !out) return PTX_ERR_BAD_ARG;

@@ -98,7 +98,7 @@ class PathTracer:
             self.set_option(k, v)
 
     DEFAULT_OPTIONS = dict(kernel_family=-1, upload_path=-1, claim_tile=0, claim_guided=-1, claim_paced=-1, claim_cap=-1, claim_ranges=0, split_samples=1, split_small=-1, split_chunk=0, share_walk=0, share_post=0,
-                           share_march=0, share_leaf=0, walk_mode=-1, grid_per_cu=0, flights=0, sorted_pool=-1, pool_over=-1, idle_whole=1, pool_paths=0)
+                           share_march=0, share_leaf=0, walk_mode=-1, grid_per_cu=0, flights=0, sorted_pool=-1, pool_over=-1, host_waits_per_frame=-1, pool_paths=0)
 
     def reset_options(self):
         self.set_options(**self.DEFAULT_OPTIONS)
@@ -215,6 +215,10 @@ class PathTracer:
     def launch_info(self) -> str:
         """What the launch policy chose for the latest trace call: kernel, job form, reservation size, counters, pools, flights."""
         return self.lib.ptx_last_launch_info(self.h).decode()
+
+    def launch_plan(self, n: int) -> str:
+        """What a trace_n of n samples would run now (the launch policy's row for that length), without launching."""
+        return self.lib.ptx_launch_plan(self.h, int(n)).decode()
 
     def kernel_time(self) -> Tuple[float, int]:
         ms, n = C.c_float(), C.c_uint32()

@@ -25,7 +25,7 @@ def main(out_path):
     for name in scenes:
         sc = host.Scene.from_fixture(os.path.join(ROOT, "data", "scenes", name + ".npz")).build(decode_textures=False)
         pt.reset_options()
-        pt.set_option("idle_whole", 0)
+        pt.set_option("host_waits_per_frame", 0)
         sc.upload_to(pt)
         per = {}
         for (w, h) in SIZES:
@@ -39,7 +39,7 @@ def main(out_path):
                 pt.sync()
                 per[f"{w}x{h}:{n}"] = describe(pt)
         # a host that waits for every frame: one-sample launches with a read-back between them
-        pt.set_option("idle_whole", 1)
+        pt.set_option("host_waits_per_frame", -1)
         pt.resize(64, 48)
         cam = sc.camera(64, 48)
         cam[0]["max_bounces"] = 2
