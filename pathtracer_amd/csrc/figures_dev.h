@@ -568,6 +568,51 @@ PT_DEV V3 mandelbulb_iterate(V3 w, V3 p, float m, float power, float& dz) {
     dm2::sincos2(dm2::mk(b, a), &sn, &cs);  // sin / cos of b in .x, of a in .y
     return p + v3(sn.x * sn.y, cs.x, sn.x * cs.y) * pw.y;
 }
+// The same iteration in the tolerance mode (ptx_set_option "arith_mode" 1; never for camera rays): the builtins' hardware
+// forms -- v_sqrt / v_rcp (1 ulp), v_log / v_exp (log2 / exp2, 1 ulp), v_sin / v_cos (argument in revolutions, about 1e-6
+// absolute here: |angle| <= power * pi) -- which is what WGSL's accuracy bounds for these builtins are written for, instead of
+// the deterministic polynomials: about 80 issue slots instead of 270.  The two angles keep their polynomials (no hardware
+// form), with the hardware reciprocal and square root inside.
+namespace fastm {
+PT_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+PT_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PT_DEV float log2(float x) { return __builtin_amdgcn_logf(x); }
+PT_DEV float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+PT_DEV float acos(float x) {
+    const float a = dm::abs_(x);
+    const bool big = a > 0.5f;
+    const float z = big ? 0.5f * (1.0f - a) : x * x;
+    const float s = big ? sqrt(z) : x;
+    float r = dm::fma_(s * z, dm::asin_poly(z), s);
+    if (big) { r = r + r; return x < 0.0f ? DM_PI - r : r; }
+    return DM_PIO2 - r;
+}
+PT_DEV float atan2(float y, float x) {
+    const float ax = dm::abs_(x), ay = dm::abs_(y);
+    const float mx = dm::fmax_(ax, ay), mn = dm::fmin_(ax, ay);
+    if (mx == 0.0f) return 0.0f;
+    const bool big = mn > 0.4142135623730950f * mx;
+    const float t = (big ? mn - mx : mn) * rcp(big ? mn + mx : mx);
+    const float z = t * t;
+    const float p = dm::fma_(z, dm::fma_(z, dm::fma_(z, 8.05374449538e-2f, -1.38776856032e-1f), 1.99777106478e-1f), -3.33329491539e-1f);
+    float r = dm::fma_(p * z, t, t);
+    if (big) r = DM_PIO4 + r;
+    if (ay > ax) r = DM_PIO2 - r;
+    if (x < 0.0f) r = DM_PI - r;
+    return y < 0.0f ? -r : r;
+}
+}  // namespace fastm
+PT_DEV V3 mandelbulb_iterate_fast(V3 w, V3 p, float m, float power, float& dz) {
+    const float r = fastm::sqrt(m);
+    const float l = fastm::log2(r);
+    const float rp = fastm::exp2(power * l);  // r^power; m^((power - 1) / 2) = r^(power - 1)
+    dz = dm::fma_(power * fastm::exp2((power - 1.0f) * l), dz, 1.0f);
+    const float k = power * 0.15915494309189535f;  // angles in revolutions
+    const float b = k * fastm::acos(clampf(w.y * fastm::rcp(r), -1.0f, 1.0f));
+    const float a = k * fastm::atan2(w.x, w.z);
+    const float sb = __builtin_amdgcn_sinf(b), cb = __builtin_amdgcn_cosf(b), sa = __builtin_amdgcn_sinf(a), ca = __builtin_amdgcn_cosf(a);
+    return p + v3(sb * sa, cb, sb * ca) * rp;
+}
 PT_DEV float sdf_mandelbulb(V3 p, float power, int max_iter) {  // mandelbulb.wgsl:5-30
     V3 w = p;
     float m = dot(w, w);
@@ -890,7 +935,7 @@ PT_DEV void frac_eval_begin(const DPrim& g, V3 p, FracIter& f) {
     }
 }
 // Returns true, with the estimator's value, when the evaluation is complete.
-PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value) {
+PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value, bool fast = false) {
     if (g.type == FIG_MANDELBULB) {  // mandelbulb.wgsl:5-30
         const float power = g.p[4];
         const uint32_t max_iter = (uint32_t)(int)g.p[5];
@@ -899,7 +944,7 @@ PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value) {
         if (!done) {
             PT_SITE(44);
             V3 w = v3(f.s[0], f.s[1], f.s[2]), p = v3(f.s[5], f.s[6], f.s[7]);
-            w = mandelbulb_iterate(w, p, m, power, dz);
+            w = fast ? mandelbulb_iterate_fast(w, p, m, power, dz) : mandelbulb_iterate(w, p, m, power, dz);
             m = dot(w, w);
             f.s[0] = w.x; f.s[1] = w.y; f.s[2] = w.z;
             f.s[3] = m;
@@ -908,6 +953,10 @@ PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value) {
             done = m > 256.0f || f.i >= max_iter;
         }
         if (!done) return false;
+        if (fast) {  // ln m = log2 m * ln 2
+            value = 0.25f * (fastm::log2(m) * 0.69314718055994531f) * fastm::sqrt(m) * fastm::rcp(dz);
+            return true;
+        }
         float r = dm::sqrt_(m);
         value = dm::div_(0.25f * dm::log_(m) * r, dz);
         return true;
@@ -933,6 +982,11 @@ PT_DEV bool frac_eval_iter(const DPrim& g, FracIter& f, float& value) {
         done = f.i >= max_iter || r2 > 16.0f;
     }
     if (!done) return false;
+    if (fast) {  // the iteration is plain arithmetic in both modes; only the closing expression has builtins
+        const float rr = fastm::sqrt(r2);
+        value = 0.5f * rr * (fastm::log2(rr) * 0.69314718055994531f) * __builtin_amdgcn_rsqf(dot4(dz, dz));
+        return true;
+    }
     float r = dm::sqrt_(r2);
     float dr = dm::sqrt_(dot4(dz, dz));
     value = dm::div_(0.5f * r * dm::log_(r), dr);

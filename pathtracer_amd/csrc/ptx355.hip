@@ -625,13 +625,13 @@ PT_DEV void sched_body(const TraceParams& P) {
             __builtin_amdgcn_s_sleep(8);
         } else if (pick == LS_WALK) {
             for (;;) {
-                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, single, frac);
+                if (S == LS_WALK) S = walk_step<FRAC>(sc, tv, st, P.cam.fractal_march_steps, single, frac, FRAC ? P.frac_fast : 0u);
                 const uint32_t w = (uint32_t)__popcll(__ballot(S == LS_WALK));
                 if (w == 0u || w * P.share_walk < live) break;
                 if (single != 0u && (uint32_t)__popcll(__ballot(S == LS_LEAF)) * P.share_leaf >= live) break;
             }
         } else if (pick == LS_LEAF) {
-            if (S == LS_LEAF) S = leaf_step<FRAC>(sc, tv, P.cam.fractal_march_steps, single, frac);
+            if (S == LS_LEAF) S = leaf_step<FRAC>(sc, tv, P.cam.fractal_march_steps, single, frac, FRAC ? P.frac_fast : 0u);
         } else if (pick == LS_POST) {
             if (S == LS_POST) {
                 if (PARK_JOB) {
@@ -658,7 +658,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                 T.ray.o = v3(0.0f, 0.0f, 0.0f); T.ray.d = v3(0.0f, 0.0f, 1.0f);
                 T.m.t = 0.0f; T.m.prev_d = 0.0f; T.m.max_t = 0.0f; T.m.i = 0u;
                 for (int k9 = 0; k9 < 9; k9++) T.f.s[k9] = 0.0f;
-                T.f.i = 0u; T.phase = 0u; T.ref = 0u; T.nacc = v3(0.0f, 0.0f, 0.0f);
+                T.f.i = 0u; T.phase = 0u; T.ref = 0u; T.fast = 0u; T.nacc = v3(0.0f, 0.0f, 0.0f);
                 uint32_t rot = wave * 16u;  // where this wave's free lanes start looking: moves on every pass, differs between waves
                 for (;;) {
                     PT_SITE_HIST(60, live);
@@ -729,7 +729,7 @@ PT_DEV void sched_body(const TraceParams& P) {
                         // lanes whose evaluation has ended wait for company: the code that follows an evaluation runs when
                         // FRAC_GLUE_MIN lanes want it (or the pass is over), and those lanes then iterate on with their next evaluation
                         for (int it = 0; it < FRAC_ITERS_PER_PASS && cur != nullptr; it++) {
-                            if (!ended) ended = frac_eval_iter(g, T.f, value);
+                            if (!ended) ended = frac_eval_iter(g, T.f, value, T.fast != 0u);
                             const bool last = it + 1 == FRAC_ITERS_PER_PASS;
                             if ((uint32_t)__popcll(__ballot(ended)) >= (uint32_t)FRAC_GLUE_MIN || last) {
                                 if (ended) {
@@ -1083,6 +1083,7 @@ struct ptx_ctx {
         uint32_t shares[4] = {0u, 0u, 0u, 0u};  // walk, post, march, leaf; 0 per scene
         int walk_mode = -1;       // -1 per scene, 0 / 1 / 2 (TraceParams::walk_single)
         int sorted_pool = -1;     // -1 per scene and launch, 0 / 1: lockstep LDS kernel over sorted path pools (sample jobs, long launches)
+        int arith_mode = 0;       // 0 exact (bit for bit the oracle's arithmetic), 1 tolerance mode of the fractal estimators (sched_dev.h, frac_fast)
         int host_waits = -1;      // host_waits_per_frame: -1 by the call sequence, 0 one-sample launches always overlap, 1 they never do (launch_trace)
         int pool_over = -1;       // -1 per scene (4; lit meshes 0): launches of more samples than this may trace from pools
         uint32_t pool_paths = 0;  // 0 = 4096, else paths per workgroup pool (a power of two from 256 to 16384)
@@ -1432,6 +1433,7 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "share_leaf") { if ((ok = in(0, 64))) o.shares[3] = (uint32_t)value; }
     else if (k == "walk_mode") { if ((ok = in(-1, 2))) o.walk_mode = (int)value; }
     else if (k == "sorted_pool") { if ((ok = in(-1, 1))) o.sorted_pool = (int)value; }
+    else if (k == "arith_mode") { if ((ok = in(0, 2))) o.arith_mode = (int)value; }
     else if (k == "host_waits_per_frame") { if ((ok = in(-1, 1))) o.host_waits = (int)value; }
     else if (k == "idle_whole") { if ((ok = in(0, 1))) o.host_waits = value ? -1 : 0; }  // the option's earlier name
     else if (k == "pool_over") { if ((ok = in(-1, 0x7FFFFFFF))) o.pool_over = (int)value; }
@@ -2058,6 +2060,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         P.share_leaf = c->share_leaf;
     }
     P.sc.lds_stack_entries = L.lds_stack;
+    P.frac_fast = c->opt.arith_mode >= 1 && form.sched && frac ? (uint32_t)c->opt.arith_mode : 0u;  // the wave-scheduled fractal kernels have the mode; the others are always exact
     if (sorted) {
         const uint32_t m = form.pool_m;
         if ((size_t)grid > c->pool_wgs || m > c->pool_m) {  // the buffers only grow: a smaller pool uses a part of each workgroup's share

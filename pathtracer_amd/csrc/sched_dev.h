@@ -57,6 +57,9 @@ struct TraceParams {
     // kernel folds the samples of each pixel into its running mean in sample order afterwards.
     uint32_t split_n, frame_pixels;
     float4* staging;
+    // Tolerance mode of the fractal kernels (the arith_mode option): marches of rays other than camera rays evaluate the distance
+    // estimators with the hardware transcendentals (mandelbulb_iterate_fast).  0: every march is exact.
+    uint32_t frac_fast;
     // Sorted path pools (ptx_trace_kernel_lds_sorted): per workgroup two buffers of pool_m path records, their keys, and the
     // order the current buffer is traced in.
     struct PoolPath* pool;
@@ -100,7 +103,7 @@ enum : uint32_t {
 #define SC_FRAC_FIELDS 19u
 enum : uint32_t {
     TK_S = 0,        // FracIter::s[0..7]
-    TK_WORD = 8,     // estimator iterations done | phase << 16 | status << 20: one word, so that a claim is one compare-and-swap
+    TK_WORD = 8,     // estimator iterations done | tolerance mode << 15 | phase << 16 | status << 20: one word, so that a claim is one compare-and-swap
     TK_REF = 9,      // the figure's primitive slot (slot_prim)
     TK_O = 10, TK_D = 13,                  // the ray
     TK_T = 16, TK_PREV = 17, TK_STEP = 18  // MarchState: t (the hit distance when done), prev_d, marching steps done
@@ -199,6 +202,7 @@ struct FracTask {
     MarchState m;
     FracIter f;
     uint32_t phase, ref;
+    uint32_t fast;  // 1: this march runs in the tolerance mode (set when it is posted; travels in TK_WORD)
     V3 nacc;  // normal tasks: the sum so far (kept in the owner's parked normal while nobody holds the task)
 };
 // Starts the estimator evaluation at distance t along the task's ray (normal phases: offset by their tetrahedron corner,
@@ -226,7 +230,7 @@ PT_DEV void task_store(float* st, const FracTask& T, uint32_t status) {
         pk[(PK_N + 0) * 64] = T.nacc.x; pk[(PK_N + 1) * 64] = T.nacc.y; pk[(PK_N + 2) * 64] = T.nacc.z;
     }
     lds_drain();
-    __hip_atomic_store(&su[TK_WORD * 64], T.f.i | (T.phase << 16) | (status << TK_STATUS_SHIFT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&su[TK_WORD * 64], T.f.i | (T.fast << 15) | (T.phase << 16) | (status << TK_STATUS_SHIFT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Takes the march at `st` (this lane's own or another lane's) if it is waiting for someone to run it.
 PT_DEV bool task_claim(const DScene& sc, float* st, uint32_t march_steps, FracTask& T) {
@@ -239,7 +243,8 @@ PT_DEV bool task_claim(const DScene& sc, float* st, uint32_t march_steps, FracTa
     PT_SITE(48);
 #pragma unroll
     for (int k = 0; k < 8; k++) T.f.s[k] = st[(TK_S + k) * 64];
-    T.f.i = word & 0xFFFFu;
+    T.f.i = word & 0x7FFFu;
+    T.fast = (word >> 15) & 1u;
     T.phase = (word >> 16) & 0xFu;
     T.ref = su[TK_REF * 64];
     T.ray.o = v3(st[(TK_O + 0) * 64], st[(TK_O + 1) * 64], st[(TK_O + 2) * 64]);
@@ -264,18 +269,20 @@ PT_DEV bool task_claim(const DScene& sc, float* st, uint32_t march_steps, FracTa
     return true;
 }
 // The owner posts a march of its ray against figure g (primitive slot ref), begun by march_begin_fractal (m), ...
-PT_DEV void task_start_march(const DPrim& g, uint32_t ref, const Ray& ray, const MarchState& m, float* frac) {
+PT_DEV void task_start_march(const DPrim& g, uint32_t ref, const Ray& ray, const MarchState& m, float* frac, uint32_t fast) {
     FracTask T;
     T.ray = ray;
     T.m = m;
     T.ref = ref;
+    T.fast = fast;
     T.nacc = v3(0.0f, 0.0f, 0.0f);
     task_begin_eval(g, T, m.t, FP_D);
     task_store(frac, T, FS_READY);
 }
 // ... or the four evaluations of the normal at the hit at distance t (finish_fractal / tet_normal).
-PT_DEV void task_start_normal(const DPrim& g, uint32_t ref, const Ray& ray, float t, float* frac) {
+PT_DEV void task_start_normal(const DPrim& g, uint32_t ref, const Ray& ray, float t, float* frac, uint32_t fast) {
     FracTask T;
+    T.fast = fast;
     T.ray = ray;
     T.m.t = t; T.m.prev_d = 0.0f; T.m.max_t = 0.0f; T.m.i = 0u;
     T.ref = ref;
@@ -360,8 +367,9 @@ PT_DEV uint32_t task_consume(const DScene& sc, Trav& tv, uint32_t kind, float* f
 }
 
 // One LEAF step: the lane tests the leaf primitive it stands at, or enters its marcher.  Returns the lane's next state.
+// frac_fast: TraceParams::frac_fast (fractal kernels).
 template <bool FRAC>
-PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint32_t mode, float* frac) {
+PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint32_t mode, float* frac, uint32_t frac_fast = 0u) {
     const DPrim& g = sc.prims[tv.pi];
     const uint32_t type = g.type;
     bool hit = false;
@@ -373,7 +381,10 @@ PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint
         if (march_begin_mebius(tv.ray, g, tv.m)) return LS_MEBIUS;
     } else if (FRAC && (type == FIG_MANDELBULB || type == FIG_JULIA)) {
         if (march_begin_fractal(tv.ray, g, march_steps, tv.m)) {
-            task_start_march(g, tv.pi, tv.ray, tv.m, frac);
+            // the tolerance mode never touches a camera ray: its closest hit is the pixel's primary id (the path's bounce
+            // count is in the parked word; an occlusion ray belongs to a bounce's shading, not to the id)
+            const uint32_t fast = frac_fast != 0u && (frac_fast >= 2u || tv.shadow || (((const uint32_t*)task_park(frac))[PK_MISC * 64] & 0xFFFFFFu) != 0u) ? 1u : 0u;
+            task_start_march(g, tv.pi, tv.ray, tv.m, frac, fast);
             return type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
         }
     } else if (type != FIG_SKIP) {
@@ -393,7 +404,7 @@ PT_DEV uint32_t leaf_step(const DScene& sc, Trav& tv, uint32_t march_steps, uint
 // scene: 9.7 lanes per node-pair test, 2.6 per triangle test); served as states of their own, the primitive
 // tests run for the lanes that have gathered at leaves.
 template <bool FRAC>
-PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, uint32_t mode, float* frac) {
+PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint32_t march_steps, uint32_t mode, float* frac, uint32_t frac_fast = 0u) {
     const bool single = mode == 1u;
     bool walked = false;
     while (tv.pi >= tv.pend) {
@@ -436,7 +447,7 @@ PT_DEV uint32_t walk_step(const DScene& sc, Trav& tv, const WalkStack& st, uint3
         }
     }
     if (mode != 0u && walked) return LS_LEAF;
-    return leaf_step<FRAC>(sc, tv, march_steps, mode, frac);
+    return leaf_step<FRAC>(sc, tv, march_steps, mode, frac, frac_fast);
 }
 
 // One MARCH step of marcher `kind` (wave-uniform).
@@ -806,7 +817,7 @@ PT_DEV uint32_t post_step(const DScene& sc, const TraceParams& P, Trav& tv, floa
             const DPrim& gw = slot_prim(sc, tv.slot);
             if (gw.type == FIG_MANDELBULB || gw.type == FIG_JULIA) {
                 park_u[PK_MISC * 64] = bounce | (attempt << 24);  // the planes may have moved bound / slot: those live in tv
-                task_start_normal(gw, tv.slot, tv.ray, tv.bound, frac);
+                task_start_normal(gw, tv.slot, tv.ray, tv.bound, frac, P.frac_fast != 0u && (P.frac_fast >= 2u || bounce != 0u) ? 1u : 0u);
                 return gw.type == FIG_MANDELBULB ? LS_MANDEL : LS_JULIA;
             }
         }

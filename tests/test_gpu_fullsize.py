@@ -155,3 +155,68 @@ def test_job_handout_at_full_size_does_not_change_the_frame(pt, name, w, h):
         assert same_bits(got[0], ref[0]) == 0 and (got[1] == ref[1]).all() and got[2] == ref[2]
     pt.reset_options()
     sc.upload_to(pt)
+
+
+def test_fractals_1080p_128_samples_in_one_launch(pt):
+    """The benchmark's fractal launch shape: 1920 x 1080 at 128 samples in ONE launch -- 4.25 GB of staged samples, right at the
+    4 GiB bound of a chunk -- is deterministic, equals the same frames staged in forced chunks of 48 samples, and equals the
+    oracle on a tile across the Mandelbulb's silhouette (ids, mean, rgba8, bit for bit)."""
+    sc = host.Scene.from_fixture(fixture("fractals")).build()
+    w, h, n = 1920, 1080, 128
+    cam = sc.camera(w, h)
+    pt.reset_options()
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, n)
+    info = pt.launch_info()
+    assert "ptx_sched_kernel_lds_frac jobs=samples" in info and "chunk=128" in info, info
+    a, ids, out = pt.read_accum(), pt.read_primary_ids(), pt.read_output()
+    st = pt.stats()
+    assert st["paths"] == w * h * n and np.isfinite(a).all()
+    pt.clear()
+    pt.trace_n(cam, 0, 1, n)
+    assert same_bits(pt.read_accum(), a) == 0 and (pt.read_primary_ids() == ids).all()
+    pt.set_option("split_chunk", 48)
+    pt.clear()
+    pt.trace_n(cam, 0, 1, n)
+    assert "chunk=48" in pt.launch_info()
+    assert same_bits(pt.read_accum(), a) == 0 and (pt.read_primary_ids() == ids).all() and (pt.read_output() == out).all()
+    st2 = pt.stats()
+    assert (st2["paths"], st2["bounces"], st2["shadow_rays"]) == (st["paths"], st["bounces"], st["shadow_rays"])
+    pt.reset_options()
+    # a tile that holds fractal and background pixels: found from the ids the GPU reports, checked against the oracle
+    sb = hp.prepare_fixture(fixture("fractals"))
+    frac_figs = [i for i, t in enumerate(sb.figs["shape_type"]) if int(t) in (9, 10)]
+    on = np.isin(ids, frac_figs)
+    ys, xs = np.nonzero(on[:, :-1] != on[:, 1:])
+    assert len(xs) > 100
+    k = len(xs) // 2
+    x0, y0 = max(0, int(xs[k]) - 12), max(0, int(ys[k]) - 8)
+    tile = (min(x0, w - 24), min(y0, h - 16), 24, 16)
+    ref = orc.render(orc.OracleScene(sb), hp.camera_to_gpu(sb.camera, w, h), n, tile=tile)
+    sl = (slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2]))
+    assert 0 < on[sl].sum() < on[sl].size
+    assert (ids[sl] == ref["primary_id"][sl]).all()
+    assert same_bits(a[sl], ref["accum"][sl]) == 0 and (out[sl] == ref["rgba8"][sl]).all()
+
+
+def test_cornell_1080p_64_samples_from_the_large_pools(pt):
+    """Launches of 64 samples and more trace from pools of 8192 paths per workgroup: the 1080p frame against three oracle tiles."""
+    sc = host.Scene.from_fixture(fixture("cornell_box")).build()
+    w, h, n = 1920, 1080, 64
+    cam = sc.camera(w, h)
+    pt.reset_options()
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    pt.trace_n(cam, 0, 1, n)
+    info = pt.launch_info()
+    assert "ptx_trace_kernel_lds_sorted jobs=pools" in info and "pool=8192" in info, info
+    a, ids, out = pt.read_accum(), pt.read_primary_ids(), pt.read_output()
+    assert pt.stats()["paths"] == w * h * n
+    sb = hp.prepare_fixture(fixture("cornell_box"))
+    ocam = hp.camera_to_gpu(sb.camera, w, h)
+    osc = orc.OracleScene(sb)
+    for tile in [(0, 0, 40, 24), (1000, 600, 40, 24), (1880, 1056, 40, 24)]:
+        ref = orc.render(osc, ocam, n, tile=tile)
+        sl = (slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2]))
+        assert same_bits(a[sl], ref["accum"][sl]) == 0 and (ids[sl] == ref["primary_id"][sl]).all() and (out[sl] == ref["rgba8"][sl]).all()
