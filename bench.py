@@ -243,7 +243,7 @@ def run_workload(name: str, args, D: Dist, steps: int, warmup: int, spp_override
         s_elapsed = D.max_over_ranks(time.perf_counter() - t0)
         strong = {"scaling": "strong", "total_spp": total_spp, "spp_per_rank": [c for _, c in share], "value": round(w * h * total_spp / s_elapsed / 1e6, 2),
                   "unit": "Mpaths/s", "ms_total": round(s_elapsed * 1e3, 3),
-                  "note": "whole-job rate of one 1024-spp render split over the ranks by frame index, merge included; at N = 1 this is the headline run"}
+                  "note": f"whole-job rate of one {total_spp}-spp render split over the ranks by frame index, merge included; at N = 1 this is the headline run"}
 
     out = None
     if rank == 0:

@@ -146,7 +146,7 @@ PT_DEV void trace_body(const TraceParams& P) {
         ps.ray = generate_ray(P.cam, ps.rng, (float)J.px, (float)J.py);
     }
 #ifdef PTX_PHASE_TIMING
-    for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
+    for (int i = 0; i < PT_NTICKS; i++) ps.tick_acc[i] = 0;
     ps.tick_last = clock64();
     const unsigned long long wall0 = wall_clock64();
 #endif
@@ -230,6 +230,7 @@ PT_DEV void trace_body(const TraceParams& P) {
 #ifdef PTX_PHASE_TIMING
     if (lane == 0u && P.stats) {
         for (int i = 0; i < 6; i++) atomicAdd(&P.stats[4 + i], (unsigned long long)ps.tick_acc[i]);
+        for (int i = 6; i < PT_NTICKS; i++) atomicAdd(&P.stats[10 + i], (unsigned long long)ps.tick_acc[i]);
         const unsigned long long wall1 = wall_clock64();  // 100 MHz
         atomicMax(&P.stats[10], ~wall0);
         atomicMax(&P.stats[11], wall1);
@@ -361,8 +362,12 @@ PT_DEV void sorted_body(const TraceParams& P) {
     uint32_t n_shadow = 0u, n_bounce = 0u, n_paths = 0u, parity = 0u;
     PathState ps;
 #ifdef PTX_PHASE_TIMING
-    for (int i = 0; i < 6; i++) ps.tick_acc[i] = 0;
+    for (int i = 0; i < PT_NTICKS; i++) ps.tick_acc[i] = 0;
     ps.tick_last = clock64();
+    const unsigned long long wall0 = wall_clock64();
+#define WG_SYNC_T(slot) do { PT_TICK(slot); wg_sync(); PT_TICK(10); } while (0)
+#else
+#define WG_SYNC_T(slot) wg_sync()
 #endif
     for (;;) {
         PoolPath* const cur = buf0 + (size_t)parity * M;
@@ -380,7 +385,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
                 if (base + need >= P.total_jobs) cv[4] = 1u;  // the launch's last jobs are among these
             }
         }
-        wg_sync();
+        WG_SYNC_T(6);
         {
             const uint32_t need = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[5]);
             const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[3]);
@@ -403,7 +408,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
         }
         if (threadIdx.x < RG_BINS) hist[threadIdx.x] = 0u;
         if (threadIdx.x == RG_BINS) { cv[1] = 0u; cv[2] = 0u; }
-        wg_sync();
+        WG_SYNC_T(6);
         uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[0]);
         const uint32_t no_jobs_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[4]);
         if (count > M) count = M;
@@ -413,24 +418,24 @@ PT_DEV void sorted_body(const TraceParams& P) {
             // top-up has to go on reserving.  The barrier keeps thread 0 from writing the next round's flags while the other
             // waves still read this round's.
             if (no_jobs_left != 0u || P.n == 0u) break;
-            wg_sync();
+            WG_SYNC_T(6);
             continue;
         }
         // ---- sort: the order the current buffer is traced in
         for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
-        wg_sync();
+        WG_SYNC_T(7);
         if (wave == 0u) {
             const uint32_t a = hist[2u * lane], b = hist[2u * lane + 1u];
             const uint32_t incl = wave_incl_scan(a + b);
             offs[2u * lane] = incl - (a + b);
             offs[2u * lane + 1u] = incl - b;
         }
-        wg_sync();
+        WG_SYNC_T(7);
         for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) {
             const uint32_t pos = atomicAdd(&offs[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
             if (pos < M) order[pos] = (uint16_t)i;
         }
-        wg_sync();
+        WG_SYNC_T(7);
         // ---- trace: one bounce of every path of the buffer, 64 at a time in sorted order.  A wave claims its next chunk and
         // reads that chunk's places in the order before it traces the current one: only the records' load waits on memory.
         auto claim_chunk = [&](uint32_t& chunk, uint32_t& idx) {
@@ -458,6 +463,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
             ps.radiance = v3(q3.x, q3.y, q3.z);
             uint32_t primary = __float_as_uint(q3.w);
             claim_chunk(chunk_n, idx_n);
+            PT_TICK(8);
             bool keep = false;
             if (have) {
                 bool done = true;
@@ -495,11 +501,23 @@ PT_DEV void sorted_body(const TraceParams& P) {
                     }
                 }
             }
+            PT_TICK(9);
         }
-        wg_sync();  // every chunk is done, every append made
+        WG_SYNC_T(9);  // every chunk is done, every append made
         if (threadIdx.x == 0u) cv[0] = cv[1];
         parity ^= 1u;
     }
+#ifdef PTX_PHASE_TIMING
+    if (lane == 0u && P.stats) {
+        for (int i = 0; i < 6; i++) atomicAdd(&P.stats[4 + i], (unsigned long long)ps.tick_acc[i]);
+        for (int i = 6; i < PT_NTICKS; i++) atomicAdd(&P.stats[10 + i], (unsigned long long)ps.tick_acc[i]);
+        const unsigned long long wall1 = wall_clock64();
+        atomicMax(&P.stats[10], ~wall0);
+        atomicMax(&P.stats[11], wall1);
+        atomicAdd(&P.stats[12], wall1 - wall0);
+        atomicAdd(&P.stats[13], 1ull);
+    }
+#endif
     const uint32_t sp = wave_sum(n_paths), sb = wave_sum(n_bounce), ss = wave_sum(n_shadow);
     if (lane == 0u && P.stats) {
         atomicAdd(&P.stats[0], (unsigned long long)sp);
@@ -1360,8 +1378,8 @@ int ptx_create(int device, ptx_ctx** out) {
     ptx_ctx* c = new ptx_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&c->stats, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->stats, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->stats, 24 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->stats, 0, 24 * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return PTX_ERR_HIP;
     }
@@ -1976,7 +1994,7 @@ int ptx_clear(ptx_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->out, 0, n * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ids, 0xFF, n * 4, c->stream));
     if (c->m2) HIP_TRY(c, hipMemsetAsync(c->m2, 0, n * 12, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 24 * sizeof(unsigned long long), c->stream));
     return PTX_OK;
 }
 
@@ -2701,11 +2719,13 @@ const char* ptx_launch_plan(ptx_ctx* c, uint32_t n) {
 
 int ptx_read_stats(ptx_ctx* c, ptx_stats* out) {
     if (!c || !out) return PTX_ERR_BAD_ARG;
-    unsigned long long v[16];
+    unsigned long long v[24];
     int rc = read_back(c, v, c->stats, sizeof(v), "ptx_read_stats");
     if (rc) return rc;
 #ifdef PTX_PHASE_TIMING
     fprintf(stderr, "phase cycles: closest %llu shadeA %llu shadow %llu shadeB %llu loop-rest %llu finalize %llu\n", v[4], v[5], v[6], v[7], v[8], v[9]);
+    if (v[16] | v[17] | v[18] | v[19] | v[20])
+        fprintf(stderr, "pool cycles: top-up %llu sort %llu record-load %llu record-store+key %llu barrier-wait %llu\n", v[16], v[17], v[18], v[19], v[20]);
     if (v[13]) fprintf(stderr, "waves %llu: first start to last end %.3f ms, mean wave lifetime %.3f ms (lane 0 of each wave)\n", v[13], (double)(v[11] - ~v[10]) * 1e-5, (double)v[12] / (double)v[13] * 1e-5);
 #endif
     out->paths = v[0]; out->bounces = v[1]; out->shadow_rays = v[2];

@@ -637,6 +637,8 @@ PT_DEV Ray generate_ray(const ptx_camera& cam, uint32_t& rng, float fx, float fy
 }
 
 // Optional per-phase cycle attribution (diagnostic builds only: -DPTX_PHASE_TIMING).
+#define PT_NTICKS 11  // 0 closest hit, 1 shading up to the occlusion query, 2 occlusion query, 3 shading after it, 4 loop rest, 5 sample hand-over;
+                      // pools: 6 top-up, 7 sort, 8 record load, 9 record store + key, 10 waiting at workgroup barriers
 #ifdef PTX_PHASE_TIMING
 static __device__ __forceinline__ void pt_tick_impl(unsigned long long* acc, unsigned long long& last, int i) {
     unsigned long long now = clock64();
@@ -655,7 +657,7 @@ struct PathState {
     V3 throughput, radiance;
     uint32_t rng, bounce;
 #ifdef PTX_PHASE_TIMING
-    unsigned long long tick_acc[6], tick_last;
+    unsigned long long tick_acc[PT_NTICKS], tick_last;
 #endif
 };
 #define PT_PARK_FIELDS 23u  // per-lane LDS slots for values parked across the occlusion query
