@@ -377,11 +377,22 @@ PT_DEV void sorted_body(const TraceParams& P) {
         // ---- top-up: new paths for the places of those that ended
         if (threadIdx.x == 0u) {
             const uint32_t have = cv[0];
-            const uint32_t need = (cv[4] != 0u || P.n == 0u || have >= M) ? 0u : M - have;
+            uint32_t need = (cv[4] != 0u || P.n == 0u || have >= M) ? 0u : M - have;
+            if (need > 0u && P.pool_guided != 0u) {
+                // Never more than 1 / (pool_guided x workgroups) of the jobs that were left at this workgroup's previous reservation
+                // (at least 256): large while there is plenty, small at the end, so that the launch's last jobs are spread over all
+                // workgroups instead of filling the pools of a few (a short launch is a handful of fills per workgroup, and pixels
+                // differ in cost).
+                const uint32_t seen = cv[6];
+                uint32_t cap = (P.total_jobs > seen ? P.total_jobs - seen : 0u) / (gridDim.x * P.pool_guided);
+                cap = cap < 256u ? 256u : cap;
+                need = need < cap ? need : cap;
+            }
             cv[5] = need;
             if (need > 0u) {
                 const uint32_t base = atomicAdd(P.job_counter, need);
                 cv[3] = base;
+                cv[6] = base + need;
                 if (base + need >= P.total_jobs) cv[4] = 1u;  // the launch's last jobs are among these
             }
         }
@@ -421,21 +432,27 @@ PT_DEV void sorted_body(const TraceParams& P) {
             WG_SYNC_T(6);
             continue;
         }
+        // The launch's last paths: no job is left to top the pool up with and what remains is a fraction of a round.  Rounds of a
+        // shrinking pool cost their sort and barriers for a few paths each; instead every path left is traced to its end by the
+        // lane that takes it, unsorted, and the workgroup is done.
+        const bool finish = no_jobs_left != 0u && count <= P.pool_finish;
         // ---- sort: the order the current buffer is traced in
-        for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
-        WG_SYNC_T(7);
-        if (wave == 0u) {
-            const uint32_t a = hist[2u * lane], b = hist[2u * lane + 1u];
-            const uint32_t incl = wave_incl_scan(a + b);
-            offs[2u * lane] = incl - (a + b);
-            offs[2u * lane + 1u] = incl - b;
+        if (!finish) {
+            for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) atomicAdd(&hist[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
+            WG_SYNC_T(7);
+            if (wave == 0u) {
+                const uint32_t a = hist[2u * lane], b = hist[2u * lane + 1u];
+                const uint32_t incl = wave_incl_scan(a + b);
+                offs[2u * lane] = incl - (a + b);
+                offs[2u * lane + 1u] = incl - b;
+            }
+            WG_SYNC_T(7);
+            for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) {
+                const uint32_t pos = atomicAdd(&offs[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
+                if (pos < M) order[pos] = (uint16_t)i;
+            }
+            WG_SYNC_T(7);
         }
-        WG_SYNC_T(7);
-        for (uint32_t i = threadIdx.x; i < count; i += PTX_BLOCK) {
-            const uint32_t pos = atomicAdd(&offs[(uint32_t)cur_keys[i] & (RG_BINS - 1u)], 1u);
-            if (pos < M) order[pos] = (uint16_t)i;
-        }
-        WG_SYNC_T(7);
         // ---- trace: one bounce of every path of the buffer, 64 at a time in sorted order.  A wave claims its next chunk and
         // reads that chunk's places in the order before it traces the current one: only the records' load waits on memory.
         auto claim_chunk = [&](uint32_t& chunk, uint32_t& idx) {
@@ -443,7 +460,7 @@ PT_DEV void sorted_body(const TraceParams& P) {
             if (lane == 0u) c2 = atomicAdd(&cv[2], 1u);
             chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)c2);
             const uint32_t i2 = chunk * 64u + lane;
-            idx = (chunk * 64u < count && i2 < count) ? (uint32_t)order[i2] : 0u;
+            idx = (chunk * 64u < count && i2 < count) ? (finish ? i2 : (uint32_t)order[i2]) : 0u;
         };
         uint32_t chunk_n, idx_n;
         claim_chunk(chunk_n, idx_n);
@@ -467,15 +484,17 @@ PT_DEV void sorted_body(const TraceParams& P) {
             bool keep = false;
             if (have) {
                 bool done = true;
-                if (ps.bounce < P.cam.max_bounces) {
-                    uint32_t fig;
-                    n_bounce += 1u;
-                    const bool first = ps.bounce == 0u;
-                    done = bounce_step<FRAC, !LDS_SCENE>(sc, P.cam, ps, st, park, fig, n_shadow);
-                    PT_TICK(3);
-                    if (first) primary = fig;
-                    if (!done && ps.bounce >= P.cam.max_bounces) done = true;
-                }
+                do {
+                    if (ps.bounce < P.cam.max_bounces) {
+                        uint32_t fig;
+                        n_bounce += 1u;
+                        const bool first = ps.bounce == 0u;
+                        done = bounce_step<FRAC, !LDS_SCENE>(sc, P.cam, ps, st, park, fig, n_shadow);
+                        PT_TICK(3);
+                        if (first) primary = fig;
+                        if (!done && ps.bounce >= P.cam.max_bounces) done = true;
+                    }
+                } while (finish && !done);
                 if (done) {
                     PT_SITE(36);
                     PixelJob J;
@@ -1082,6 +1101,7 @@ struct ptx_ctx {
     uint32_t split_upto = 0x7FFFFFFFu;  // launches of up to this many samples use them (the split_small option)
     bool plain_mesh = false;      // wave-scheduled, no marched figures, shallow tree: the scenes whose paths cost least
     uint32_t type_mask = 0;       // 1 << type over the BVH primitives of the uploaded scene
+    uint32_t n_marched = 0;       // torus / Moebius figures among them
     const char* last_kernel = nullptr;  // the trace kernel of the latest launch since the scene was uploaded
     std::string last_info;              // ... and what else the launch policy chose for it (ptx_last_launch_info)
     std::string plan_info;              // ptx_launch_plan's answer
@@ -1105,6 +1125,10 @@ struct ptx_ctx {
         int host_waits = -1;      // host_waits_per_frame: -1 by the call sequence, 0 one-sample launches always overlap, 1 they never do (launch_trace)
         int pool_over = -1;       // -1 per scene (4; lit meshes 0): launches of more samples than this may trace from pools
         uint32_t pool_paths = 0;  // 0 = 4096, else paths per workgroup pool (a power of two from 256 to 16384)
+        int pool_guided = -1;     // -1 = 0: a top-up reserves what the pool lacks; k: at most 1/(k * workgroups) of the jobs left (measured: helps
+                                  // rings.yaml at one sample per launch, 1.50 -> 0.90 ms with k = 4, costs the Cornell box 0.855 -> 0.917)
+        int pool_spread = -1;     // -1 one-sample launches only; 1: a pool's reservation samples the frame at a stride (job_pixel, job_transposed); 0: block order
+        int pool_finish = -1;     // -1 = 256; with no job left, a pool of up to this many paths is traced to the end without further rounds
         uint32_t grid_per_cu = 0; // 0 = every resident workgroup
         int64_t split_upto = -1;  // split_small: -1 per scene, else launches of up to this many samples run sample jobs (fractal scenes on the scheduled kernels always do)
         uint32_t flights = 0;     // launches of sample-granular jobs in flight at once; 0 = as many as the staging bound allows (at most PTX_FLIGHTS)
@@ -1122,6 +1146,12 @@ struct ptx_ctx {
         size_t wave_state_n = 0;
         StackEntry* spill = nullptr;  // deep-stack entries of its waves (scenes that need them)
         size_t spill_waves = 0;
+        // its set of sorted path pools (launches that trace from pools): for pool_wgs workgroups, pool_m paths each
+        PoolPath* pool = nullptr;
+        uint8_t* pool_keys = nullptr;
+        uint16_t* pool_order = nullptr;
+        size_t pool_wgs = 0;
+        uint32_t pool_m = 0;
     };
     Flight flights[PTX_FLIGHTS];
     uint32_t flight_seq = 0;
@@ -1136,12 +1166,6 @@ struct ptx_ctx {
     WaveState* wave_state = nullptr;  // claim record of every wave of the largest grid so far (the kernels initialise their own)
     size_t wave_state_n = 0;
     unsigned char* static_scratch = nullptr;  // this device's copy of ptx_static_scratch (its address, not the host-side symbol)
-    // sorted path pools (ptx_trace_kernel_lds_sorted): for pool_wgs workgroups, pool_m paths each
-    PoolPath* pool = nullptr;
-    uint8_t* pool_keys = nullptr;
-    uint16_t* pool_order = nullptr;
-    size_t pool_wgs = 0;
-    uint32_t pool_m = 0;
     // multi-GPU exchange (collective.h)
     ncclComm_t comm = nullptr;
     bool comm_owned = false;      // created by ptx_comm_init (destroyed with the context) or handed in by ptx_comm_adopt
@@ -1415,11 +1439,11 @@ void ptx_destroy(ptx_ctx* c) {
         if (f.folded) (void)hipEventDestroy(f.folded);
         if (f.wave_state) (void)hipFree(f.wave_state);
         if (f.spill) (void)hipFree(f.spill);
+        if (f.pool) (void)hipFree(f.pool);
+        if (f.pool_keys) (void)hipFree(f.pool_keys);
+        if (f.pool_order) (void)hipFree(f.pool_order);
     }
     if (c->flight_counters) (void)hipFree(c->flight_counters);
-    if (c->pool) (void)hipFree(c->pool);
-    if (c->pool_keys) (void)hipFree(c->pool_keys);
-    if (c->pool_order) (void)hipFree(c->pool_order);
     if (c->barrier) (void)hipEventDestroy(c->barrier);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1456,6 +1480,9 @@ int ptx_set_option(ptx_ctx* c, const char* key, int64_t value) {
     else if (k == "idle_whole") { if ((ok = in(0, 1))) o.host_waits = value ? -1 : 0; }  // the option's earlier name
     else if (k == "pool_over") { if ((ok = in(-1, 0x7FFFFFFF))) o.pool_over = (int)value; }
     else if (k == "pool_paths") { if ((ok = value == 0 || (value >= 256 && value <= 16384 && (value & (value - 1)) == 0))) o.pool_paths = (uint32_t)value; }
+    else if (k == "pool_guided") { if ((ok = in(-1, 64))) o.pool_guided = (int)value; }
+    else if (k == "pool_spread") { if ((ok = in(-1, 1))) o.pool_spread = (int)value; }
+    else if (k == "pool_finish") { if ((ok = in(-1, 16384))) o.pool_finish = (int)value; }
     else if (k == "grid_per_cu") { if ((ok = in(0, 64))) o.grid_per_cu = (uint32_t)value; }
     else if (k == "flights") { if ((ok = in(0, PTX_FLIGHTS))) o.flights = (uint32_t)value; }
     else if (k == "verbose") { o.verbose = value != 0; }
@@ -1504,6 +1531,34 @@ static size_t trace_lds_bytes(const ptx_ctx* c) {
 // The form a launch of n samples takes on the uploaded scene under the current options.  samples_allowed false: the
 // whole-pixel form (what ptx_trace_n_static, radiance capture and a host that waits for every frame run), which does not
 // depend on n.  Every choice below was measured; frames are identical under all of them (tested).
+// Launches of more samples than this may trace from sorted path pools.
+//  * Scenes staged in LDS that run the lockstep kernels (the Cornell box and most of the reference's small scenes): every launch.
+//    Short launches overlap (a pool set per flight) and beat lane-owned paths back to back -- 1080p, ms per launch of 1 / 2 / 4 samples:
+//    Cornell box 0.99 / 1.80 / 3.42 -> 0.85 / 1.53 / 2.89 (10.4 Gpath-bounce/s at the reference's own one-sample dispatch), demo.yaml
+//    0.4 / 0.7 / 1.0 -> 0.3 / 0.4 / 0.6 (profiles/r03_short_pools.txt).  Round 2 had pools lose here: one pool set per context, so
+//    short launches ran in turn, and pools of 4096 paths left half the workgroups of a one-sample launch without a job.
+//  * ... unless several ray-marched figures make pixels differ a hundredfold in cost (rings.yaml: sixteen tori): a pool reserves
+//    thousands of jobs at a time, and at one or two samples per launch a workgroup whose jobs lie on the figures ends long after
+//    the rest (0.78 / 1.46 ms lane-owned against 0.91 / 1.47 from pools); from three samples up pools win there too (2.69 -> 2.12 at four).
+//  * Small scenes with a Moebius strip (wave-scheduled below this) and scenes without the option: four.  A lit mesh's paths are long
+//    enough for pools to win at every length (unit_logo.yaml, one / four samples per launch: 430 -> 610 / 471 -> 750 Mpaths/s).
+static uint32_t pool_over_default(const ptx_ctx* c) {
+    const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
+    if (c->opt.pool_over >= 0) return (uint32_t)c->opt.pool_over;
+    if (lit_mesh) return 0u;
+    if (c->sc.lds_scene_bytes > 0u && !c->sched && c->sc.has_fractals == 0u) return c->n_marched >= 2u ? 2u : 0u;
+    return 4u;
+}
+// ... and on those LDS scenes launches of three and four samples keep lane-owned paths when the scene is walls, a light and a
+// figure or two (fewer than four primitives in the tree): there is little for a sort to bring together, and back to back the pools'
+// rounds cost 6-12 % (cube.yaml 1.27 -> 1.39 ms at four samples per launch; the Cornell box 3.43 -> 2.89, demo.yaml 1.03 -> 0.65,
+// and the scenes without lights, whose paths end after a bounce or two, 0.52 -> 0.42, gain).
+static bool short_pools_pay(const ptx_ctx* c, uint32_t n) {
+    if (c->opt.pool_over >= 0 || n <= 2u || n > 4u) return true;
+    if (!(c->sc.lds_scene_bytes > 0u && !c->sched && c->sc.has_fractals == 0u)) return true;
+    return c->sc.nprim >= 4u || c->sc.nlight == 0u;
+}
+
 static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
     const DScene& sc = c->sc;
     const bool frac = sc.has_fractals != 0u, lds = sc.lds_scene_bytes > 0u;
@@ -1514,14 +1569,10 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
     // Shallow meshes with lights (unit_logo.yaml: six bounces and five occlusion queries per path) likewise: 72 -> 44 ms per 16
     // samples at 1080p; without lights (a bounce or two into the sky) the wave-scheduled kernels are up to twice as fast as pools.
     const bool lit_mesh = c->plain_mesh && sc.nlight > 0u;
-    // Launches of more samples than this may trace from pools.  Pools do not overlap with the next launch (one set per context),
-    // lane-owned launches of up to four samples do: back to back the Cornell box loses 10-50 % at one sample per launch from
-    // pools, gains 8 % at four, rings.yaml loses 23 % at four (in turn pools win from two samples up).  A lit mesh's paths
-    // are long enough for pools to win at every length (unit_logo.yaml, one / four samples per launch: 430 -> 610 / 471 -> 750 Mpaths/s).
-    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : (lit_mesh ? 0u : 4u);
+    const uint32_t pool_over = pool_over_default(c);
     // Sample jobs + fold against whole-pixel jobs: configure().  (Sample jobs need a claiming grid: below.)
     const bool can_split = samples_allowed && c->split && n <= c->split_upto;
-    const bool pools_instead = c->opt.family < 0 && c->opt.sorted_pool != 0 && (lds || lit_mesh) && !frac && n > pool_over && can_split;
+    const bool pools_instead = c->opt.family < 0 && c->opt.sorted_pool != 0 && (lds || lit_mesh) && !frac && n > pool_over && can_split && short_pools_pay(c, n);
     f.sched = c->sched && !pools_instead;
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
@@ -1533,7 +1584,7 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
     const bool split = f.claim && can_split;
     // Long launches of sample jobs on the lockstep kernels trace from sorted path pools (sorted_body); short ones, whose
     // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !f.sched && !frac && n > pool_over && (lds ? c->opt.sorted_pool != 0 : pools_global);
+    const bool sorted = split && !f.sched && !frac && n > pool_over && short_pools_pay(c, n) && (lds ? c->opt.sorted_pool != 0 : pools_global);
     f.jobs = sorted ? JOBS_POOLS : (split ? JOBS_SAMPLES : JOBS_PIXELS);
     f.kernel = f.sched == c->sched ? trace_kernel_of(c) : (lds ? ptx_trace_kernel_lds : ptx_trace_kernel);
     if (split && f.sched && !frac) f.kernel = lds ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
@@ -1571,15 +1622,16 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
     // 0.4 % of a 128-sample one (0.7 % of 8 samples of the 10 M-triangle scene); fractal launches end on tens of milliseconds
     // of a few lanes marching whatever their length (1.9 % of 128 samples).  Longer launches of the other scenes run in turn,
     // which also keeps every kernel's duration a quantity of its own.  One set of pools per context: pools run in turn.
-    f.flights = sorted ? 1u : (c->opt.flights >= 1u ? c->opt.flights : (!frac && n > 4u ? 1u : 0u));
+    // Pools of short launches: a pool set per flight, four in flight (1080p Cornell box, one sample per launch, ms with 1 / 2 / 4 / 6
+    // in flight: 1.12 / 0.93 / 0.86 / 0.90 with 2048 paths per pool).
+    f.flights = c->opt.flights >= 1u ? c->opt.flights : (!frac && n > 4u ? 1u : (sorted ? 4u : 0u));
     return f;
 }
 
 // The table: one row per class of launch length.  The thresholds are those form_for() compares n with.
 static void build_policy(ptx_ctx* c) {
-    const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
-    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : (lit_mesh ? 0u : 4u);
-    std::vector<uint32_t> upto = {1u, 2u, 4u, 16u, 63u, pool_over, c->split_upto, 0xFFFFFFFFu};
+    const uint32_t pool_over = pool_over_default(c);
+    std::vector<uint32_t> upto = {1u, 2u, 4u, 16u, 63u, pool_over, c->split_upto, 0xFFFFFFFFu};  // the lengths form_for() compares n with
     std::sort(upto.begin(), upto.end());
     upto.erase(std::unique(upto.begin(), upto.end()), upto.end());
     c->policy.clear();
@@ -1630,6 +1682,7 @@ struct LaunchChoice {
     uint32_t chunk = 0, depth = 1;  // samples per kernel launch; launches of sample jobs in flight
     uint32_t tile0 = 0;            // jobs per reservation (of the first chunk)
     uint32_t lds_stack = 0;        // traversal-stack entries per lane in LDS
+    uint32_t grid = 0;             // workgroups
 };
 // fixed: ptx_trace_n_static.  peek: ptx_launch_plan -- the context's record of the call sequence is read, not updated.
 static LaunchChoice resolve_launch(ptx_ctx* c, uint32_t n, bool fixed, uint32_t n_blocks, bool peek) {
@@ -1685,6 +1738,23 @@ static LaunchChoice resolve_launch(ptx_ctx* c, uint32_t n, bool fixed, uint32_t 
         }
     }
     L.tile0 = L.f.claim ? reservation_jobs(c, L.f, n < L.chunk ? n : L.chunk, n_blocks) : 0u;
+    // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once.
+    L.grid = n_blocks;
+    if (L.f.claim && c->occ_per_cu >= 1) {
+        uint32_t per_cu = (uint32_t)c->occ_per_cu;  // configure(): queried when the scene was uploaded
+        if (c->opt.grid_per_cu >= 1u && c->opt.grid_per_cu < per_cu) per_cu = c->opt.grid_per_cu;
+        const uint32_t resident = c->n_cu * per_cu;
+        L.grid = n_blocks < resident ? n_blocks : resident;
+        if (fixed && L.grid > PTX_STATIC_MAX_WAVES / PTX_WAVES_PER_BLOCK) L.grid = PTX_STATIC_MAX_WAVES / PTX_WAVES_PER_BLOCK;  // fewer workgroups claim the same jobs
+    }
+    // A pool is never larger than its workgroup's share of the launch's jobs: a pool that holds twice that leaves half the
+    // workgroups without a job (a one-sample launch is 2025 jobs per workgroup at 1080p, 256 at 512 x 512).
+    if (L.f.jobs == JOBS_POOLS && !c->opt.pool_paths && L.grid > 0u) {
+        const uint64_t share = ((uint64_t)n_blocks * 256u * (n < L.chunk ? n : L.chunk) / L.grid + 63u) & ~63ull;
+        const uint32_t least = 256u;
+        const uint32_t fit = share < least ? least : (share > L.f.pool_m ? L.f.pool_m : (uint32_t)share);
+        L.f.pool_m = fit;
+    }
     return L;
 }
 static std::string describe_launch(const LaunchChoice& L) {
@@ -1941,6 +2011,11 @@ int ptx_upload_scene(ptx_ctx* c, const ptx_shape* figs, uint32_t nfig, const ptx
     c->last_kernel = nullptr;
     c->last_info.clear();
     c->type_mask = type_mask;
+    c->n_marched = 0u;  // torus / Moebius figures in the tree (their rays cost up to hundreds of times a closed-form figure's)
+    for (uint32_t s_ = 0; s_ < nprim; s_++) {
+        const uint32_t t_ = figs[prims[s_]].shape_type;
+        if (t_ == FIG_TORUS || t_ == FIG_MEBIUS) c->n_marched += 1u;
+    }
     if ((rc = configure(c))) { free_scene(c); return rc; }
     return PTX_OK;
 }
@@ -2030,15 +2105,8 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     const LaunchForm& form = L.f;
     const TraceKernel kernel = form.kernel;
     const bool claim = form.claim, split = form.jobs != JOBS_PIXELS, sorted = form.jobs == JOBS_POOLS;
-    uint32_t grid = P.n_blocks;
-    if (claim) {
-        int per_cu = c->occ_per_cu;  // configure(): queried when the scene was uploaded
-        if (per_cu < 1) return fail(c, PTX_ERR_STATE, "the trace kernel does not fit a compute unit with this scene's LDS size");
-        if (c->opt.grid_per_cu >= 1u && (int)c->opt.grid_per_cu < per_cu) per_cu = (int)c->opt.grid_per_cu;
-        const uint32_t resident = c->n_cu * (uint32_t)per_cu;
-        grid = P.n_blocks < resident ? P.n_blocks : resident;
-        if (fixed && grid > PTX_STATIC_MAX_WAVES / PTX_WAVES_PER_BLOCK) grid = PTX_STATIC_MAX_WAVES / PTX_WAVES_PER_BLOCK;  // fewer workgroups claim the same jobs
-    }
+    if (claim && c->occ_per_cu < 1) return fail(c, PTX_ERR_STATE, "the trace kernel does not fit a compute unit with this scene's LDS size");
+    const uint32_t grid = L.grid;
     const size_t waves = (size_t)grid * PTX_WAVES_PER_BLOCK;
     if (fixed) {
         if (!c->static_scratch) return fail(c, PTX_ERR_STATE, "ptx_trace_n_static: the static scratch array has no address on this device");
@@ -2080,21 +2148,12 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
     P.sc.lds_stack_entries = L.lds_stack;
     P.frac_fast = c->opt.arith_mode >= 1 && form.sched && frac ? (uint32_t)c->opt.arith_mode : 0u;  // the wave-scheduled fractal kernels have the mode; the others are always exact
     if (sorted) {
-        const uint32_t m = form.pool_m;
-        if ((size_t)grid > c->pool_wgs || m > c->pool_m) {  // the buffers only grow: a smaller pool uses a part of each workgroup's share
-            const size_t wgs = (size_t)grid > c->pool_wgs ? (size_t)grid : c->pool_wgs;
-            const uint32_t cap = m > c->pool_m ? m : c->pool_m;
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->pool) (void)hipFree(c->pool);
-            if (c->pool_keys) (void)hipFree(c->pool_keys);
-            if (c->pool_order) (void)hipFree(c->pool_order);
-            c->pool = nullptr; c->pool_keys = nullptr; c->pool_order = nullptr; c->pool_wgs = 0; c->pool_m = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->pool, wgs * 2u * cap * sizeof(PoolPath)));
-            HIP_TRY(c, hipMalloc((void**)&c->pool_keys, wgs * 2u * cap * sizeof(uint8_t)));
-            HIP_TRY(c, hipMalloc((void**)&c->pool_order, wgs * cap * sizeof(uint16_t)));
-            c->pool_wgs = wgs; c->pool_m = cap;
-        }
-        P.pool = c->pool; P.pool_keys = c->pool_keys; P.pool_order = c->pool_order; P.pool_m = m;
+        P.pool_m = form.pool_m;
+        P.pool_guided = c->opt.pool_guided >= 0 ? (uint32_t)c->opt.pool_guided : 0u;
+        P.pool_finish = c->opt.pool_finish >= 0 ? (uint32_t)c->opt.pool_finish : 256u;
+        // one sample per launch: a pool's single reservation should sample the whole frame (Cornell box 0.857 -> 0.847 ms, rings.yaml
+        // 1.48 -> 0.91); longer launches lose the locality of neighbouring pixels' staged samples (rings.yaml 128 samples 51.8 -> 55.4 ms)
+        P.job_transposed = c->opt.pool_spread >= 0 ? (uint32_t)c->opt.pool_spread : (n == 1u ? 1u : 0u);
     }
     const bool zero_based = kernel == ptx_trace_kernel_lds_ranged;
     const uint32_t ranges = form.counters;
@@ -2160,6 +2219,23 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
             }
         }
         if (needs_spill) P.stack_spill = f.spill;
+        if (sorted) {
+            const uint32_t pm = form.pool_m;
+            if ((size_t)grid > f.pool_wgs || pm > f.pool_m) {  // the buffers only grow: a smaller pool uses a part of each workgroup's share
+                const size_t wgs = (size_t)grid > f.pool_wgs ? (size_t)grid : f.pool_wgs;
+                const uint32_t cap = pm > f.pool_m ? pm : f.pool_m;
+                if (f.used) HIP_TRY(c, hipEventSynchronize(f.folded));
+                if (f.pool) (void)hipFree(f.pool);
+                if (f.pool_keys) (void)hipFree(f.pool_keys);
+                if (f.pool_order) (void)hipFree(f.pool_order);
+                f.pool = nullptr; f.pool_keys = nullptr; f.pool_order = nullptr; f.pool_wgs = 0; f.pool_m = 0;
+                HIP_TRY(c, hipMalloc((void**)&f.pool, wgs * 2u * cap * sizeof(PoolPath)));
+                HIP_TRY(c, hipMalloc((void**)&f.pool_keys, wgs * 2u * cap * sizeof(uint8_t)));
+                HIP_TRY(c, hipMalloc((void**)&f.pool_order, wgs * cap * sizeof(uint16_t)));
+                f.pool_wgs = wgs; f.pool_m = cap;
+            }
+            P.pool = f.pool; P.pool_keys = f.pool_keys; P.pool_order = f.pool_order;
+        }
         // order: after whatever other calls have enqueued on the context's stream (a clear, an upload, other kernels) and after the
         // fold that read this flight's staging buffer last
         if (c->order_dirty) { HIP_TRY(c, hipEventRecord(c->barrier, c->stream)); c->order_dirty = false; }
@@ -2178,6 +2254,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         HIP_TRY(c, hipStreamWaitEvent(c->stream, f.traced, 0));
         TraceParams F = P;
         F.split_n = 0u;
+        F.job_transposed = 0u;
         hipLaunchKernelGGL(ptx_fold_kernel, dim3(P.n_blocks), dim3(256), 0, c->stream, F);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(f.folded, c->stream));

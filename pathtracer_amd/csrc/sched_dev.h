@@ -66,6 +66,9 @@ struct TraceParams {
     uint8_t* pool_keys;     // < 128
     uint16_t* pool_order;   // pool_m <= 16384
     uint32_t pool_m;
+    uint32_t pool_guided;   // 0, or: a top-up reserves at most 1/(pool_guided * workgroups) of the jobs left (at least 256)
+    uint32_t job_transposed; // sample jobs of the pools: consecutive pixel jobs are one pixel position of consecutive blocks (job_pixel)
+    uint32_t pool_finish;   // with no job left to reserve, a pool of up to this many paths is traced to the end without further rounds
 };
 // A path between two bounces: 64 bytes = four 16-byte accesses.
 struct alignas(16) PoolPath {
@@ -474,8 +477,17 @@ struct PixelJob { uint32_t tx, ty, px, py, k; size_t pix; };
 PT_DEV bool job_pixel(const TraceParams& P, uint32_t job, PixelJob& J, bool split = false) {
     J.k = 0u;
     if (split) {
-        const uint32_t pj = job / P.split_n;
+        uint32_t pj = job / P.split_n;
         J.k = job - pj * P.split_n;
+        if (P.job_transposed != 0u) {
+            // Pools reserve thousands of consecutive jobs at a time.  In block order those are a few neighbouring 16x16 blocks, and
+            // a workgroup whose blocks lie on the scene's expensive figures ends long after the others.  Here consecutive pixel jobs
+            // are the SAME pixel position of consecutive blocks -- a reservation samples the frame at a stride of sixteen pixels, so
+            // every pool gets the frame's mix of cheap and costly pixels.  (The pools sort their rays by key anyway: nothing is lost
+            // by not starting from neighbouring pixels.)
+            const uint32_t p = pj / P.n_blocks;
+            pj = ((pj - p * P.n_blocks) << 8) | p;
+        }
         job = pj;
     }
     const uint32_t blk = (job >> 8) * P.part_world + P.part_rank, p = job & 255u;

@@ -98,7 +98,7 @@ class PathTracer:
             self.set_option(k, v)
 
     DEFAULT_OPTIONS = dict(kernel_family=-1, upload_path=-1, claim_tile=0, claim_guided=-1, claim_paced=-1, claim_cap=-1, claim_ranges=0, split_samples=1, split_small=-1, split_chunk=0, share_walk=0, share_post=0,
-                           share_march=0, share_leaf=0, walk_mode=-1, grid_per_cu=0, flights=0, sorted_pool=-1, pool_over=-1, host_waits_per_frame=-1, pool_paths=0, arith_mode=0)
+                           share_march=0, share_leaf=0, walk_mode=-1, grid_per_cu=0, flights=0, sorted_pool=-1, pool_over=-1, host_waits_per_frame=-1, pool_paths=0, arith_mode=0, pool_guided=-1, pool_finish=-1, pool_spread=-1)
 
     def reset_options(self):
         self.set_options(**self.DEFAULT_OPTIONS)

@@ -148,10 +148,14 @@ def test_job_handout_at_full_size_does_not_change_the_frame(pt, name, w, h):
 
     ref = frame((4, 1, 2), split_samples=0, claim_tile=64, claim_paced=0, claim_guided=0, claim_ranges=1)
     default = frame((4, 1, 2))
-    # no lights, in LDS: sixteen counters; a mesh without lights: wave-scheduled; a mesh with lights: path pools at every length
-    assert {"test": "ranged", "planet": "ranged", "teapot": "sched", "unit_logo": "sorted"}[name] in default[3]
-    for got in (default, frame((1, 1, 1, 1, 1, 1, 1)), frame((4, 1, 2), claim_ranges=1), frame((4, 1, 2), claim_ranges=5, claim_cap=1),
-                frame((7,), sorted_pool=0), frame((4, 1, 2), flights=1, claim_tile=512)):
+    # staged in LDS: path pools at every launch length (a pool set per flight); a mesh without lights: wave-scheduled; a mesh with
+    # lights: path pools at every length.  Lane-owned paths (pool_over 4) on a scene in LDS without lights: sixteen counters.
+    assert {"test": "sorted", "planet": "sorted", "teapot": "sched", "unit_logo": "sorted"}[name] in default[3]
+    lane_owned = frame((4, 1, 2), pool_over=4)
+    assert {"test": "ranged", "planet": "ranged", "teapot": "sched", "unit_logo": "sched"}[name] in lane_owned[3]
+    for got in (default, lane_owned, frame((1, 1, 1, 1, 1, 1, 1)), frame((4, 1, 2), claim_ranges=1, pool_over=4),
+                frame((4, 1, 2), claim_ranges=5, claim_cap=1, pool_over=4), frame((7,), sorted_pool=0), frame((4, 1, 2), flights=1, claim_tile=512),
+                frame((1, 2, 4), pool_spread=1, pool_guided=3, pool_finish=0), frame((1, 1, 3, 2), pool_spread=0, pool_finish=4096, flights=2)):
         assert same_bits(got[0], ref[0]) == 0 and (got[1] == ref[1]).all() and got[2] == ref[2]
     pt.reset_options()
     sc.upload_to(pt)

@@ -548,7 +548,7 @@ def test_every_job_is_traced_once_when_the_counters_run_out(pt):
         for split in (0, 1):
             for ranges, rep in ((16, 6), (5, 2), (2, 2)):
                 pt.reset_options()
-                pt.set_options(claim_ranges=ranges, split_samples=split)
+                pt.set_options(claim_ranges=ranges, split_samples=split, pool_over=4)  # lane-owned paths: the kernel with the counters
                 sc.upload_to(pt)
                 pt.resize(w, h)
                 for _ in range(rep):

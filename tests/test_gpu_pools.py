@@ -139,10 +139,35 @@ def test_a_reservation_wholly_outside_the_tile_does_not_end_the_workgroup(pt, w,
 
 
 def test_launch_lengths_pick_the_kernel_form(pt):
-    """Launches of up to four samples keep lane-owned paths (they overlap with their neighbours); longer ones trace from pools."""
+    """Every launch length traces from pools on the Cornell box: short launches from small pools with a pool set per flight
+    (they overlap with their neighbours), long ones from large pools in turn; lane-owned paths (pool_over 4) give the same frames."""
     sc = host.Scene.from_fixture(fixture("cornell_box")).build()
     w, h = 64, 48
     cam = sc.camera(w, h)
-    a = _render(pt, sc, cam, w, h, [(k, k + 1, 1) for k in range(12)])
+    a = _render(pt, sc, cam, w, h, [(k, k + 1, 1) for k in range(12)], host_waits_per_frame=0)
     b = _render(pt, sc, cam, w, h, [(0, 1, 12)])
-    assert _same(a, b)
+    c = _render(pt, sc, cam, w, h, [(k, k + 1, 1) for k in range(12)], pool_over=4)
+    d = _render(pt, sc, cam, w, h, [(0, 1, 1), (1, 2, 2), (3, 4, 4), (7, 8, 3), (10, 11, 2)], host_waits_per_frame=0)
+    assert _same(a, b) and _same(c, b) and _same(d, b)
+    assert "sorted" in a[5] and "sorted" in b[5] and "sorted" not in c[5] and "sorted" in d[5]
+
+
+@pytest.mark.parametrize("name,w,h", [("cornell_box", 512, 512), ("rings", 320, 200), ("test", 640, 360)])
+def test_short_launches_from_overlapping_pools(pt, name, w, h):
+    """One-, two- and four-sample launches back to back, each from the pool set of its flight, with every pool knob moved: the frame
+    of lane-owned whole-pixel jobs, and the oracle's on a tile."""
+    sc = host.Scene.from_fixture(fixture(name)).build()
+    sb = hp.prepare_fixture(fixture(name))
+    cam = sc.camera(w, h)
+    plan = [(0, 1, 1), (1, 2, 1), (2, 3, 2), (4, 5, 4), (8, 9, 1), (9, 10, 3)]
+    want = _render(pt, sc, cam, w, h, plan, split_samples=0)
+    tile = (w // 3, h // 3, 32, 16)
+    ref = orc.render(orc.OracleScene(sb), cam, 12, tile=tile, want_m2=True)
+    sl = (slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2]))
+    assert same_bits(want[0][sl], ref["accum"][sl]) == 0 and (want[2][sl] == ref["primary_id"][sl]).all()
+    for opts in (dict(), dict(flights=6), dict(flights=1), dict(pool_spread=1), dict(pool_spread=0, pool_guided=4), dict(pool_finish=0),
+                 dict(pool_finish=16384), dict(pool_paths=256, flights=3), dict(pool_over=0, pool_paths=4096)):
+        got = _render(pt, sc, cam, w, h, plan, host_waits_per_frame=0, **opts)
+        assert _same(got, want), (name, opts)
+        if name != "rings":
+            assert "sorted" in got[5], (name, opts, got[5])

@@ -61,5 +61,5 @@ for name, w, h, ns in CASES:
             pt.trace_n(cam, 0, 1, n)
             pt.sync()
         st = pt.stats()
-        print(f"{name} {w}x{h} n={n}: kernel {ms:.1f} ms  {w * h * n / ms / 1e3:.1f} Mpaths/s  {st['bounces'] / ms / 1e6:.3f} Gpath-bounce/s  "
+        print(f"{name} {w}x{h} n={n}: kernel {ms:.3f} ms  {w * h * n / ms / 1e3:.1f} Mpaths/s  {st['bounces'] / ms / 1e6:.3f} Gpath-bounce/s  "
               f"bounces/path {st['bounces'] / st['paths']:.2f} shadow/path {st['shadow_rays'] / st['paths']:.2f}  {pt.kernel_name()}", flush=True)
