@@ -1068,9 +1068,11 @@ struct LaunchForm {
     uint32_t guided_k = 0;        // reservations of 1/(k * waves) of the jobs left (0: fixed size)
     uint32_t paced_m = 0;         // reservations sized to come m * waves * 10 ns apart (0: fixed size)
     uint32_t pool_m = 0;          // JOBS_POOLS: paths per workgroup pool
+    bool spread = false;          // JOBS_POOLS: a reservation samples the frame at a stride (else block order)
+    uint32_t upto_jobs = 0;       // launches of more jobs (pixels of the tile's blocks x samples) take the row's other form (0: any size)
     uint32_t flights = 0;         // launches of sample jobs in flight at most; 0 = PTX_FLIGHTS_DEFAULT within the staging memory
 };
-struct PolicyRow { uint32_t upto; LaunchForm form; };  // launches of up to `upto` samples
+struct PolicyRow { uint32_t upto; LaunchForm form, big; };  // launches of up to `upto` samples
 
 struct ptx_ctx {
     int device = 0;
@@ -1531,35 +1533,51 @@ static size_t trace_lds_bytes(const ptx_ctx* c) {
 // The form a launch of n samples takes on the uploaded scene under the current options.  samples_allowed false: the
 // whole-pixel form (what ptx_trace_n_static, radiance capture and a host that waits for every frame run), which does not
 // depend on n.  Every choice below was measured; frames are identical under all of them (tested).
-// Launches of more samples than this may trace from sorted path pools.
+// Which launch lengths trace from sorted path pools when the pool_over option leaves it to the library.
 //  * Scenes staged in LDS that run the lockstep kernels (the Cornell box and most of the reference's small scenes): every launch.
 //    Short launches overlap (a pool set per flight) and beat lane-owned paths back to back -- 1080p, ms per launch of 1 / 2 / 4 samples:
 //    Cornell box 0.99 / 1.80 / 3.42 -> 0.85 / 1.53 / 2.89 (10.4 Gpath-bounce/s at the reference's own one-sample dispatch), demo.yaml
-//    0.4 / 0.7 / 1.0 -> 0.3 / 0.4 / 0.6 (profiles/r03_short_pools.txt).  Round 2 had pools lose here: one pool set per context, so
-//    short launches ran in turn, and pools of 4096 paths left half the workgroups of a one-sample launch without a job.
+//    0.4 / 0.7 / 1.0 -> 0.3 / 0.4 / 0.6 (profiles/r03_short_pools.txt).  With one pool set per context pools lose here: short launches
+//    then run in turn, and pools of 4096 paths leave half the workgroups of a one-sample launch without a job.
 //  * ... unless several ray-marched figures make pixels differ a hundredfold in cost (rings.yaml: sixteen tori): a pool reserves
 //    thousands of jobs at a time, and at one or two samples per launch a workgroup whose jobs lie on the figures ends long after
 //    the rest (0.78 / 1.46 ms lane-owned against 0.91 / 1.47 from pools); from three samples up pools win there too (2.69 -> 2.12 at four).
-//  * Small scenes with a Moebius strip (wave-scheduled below this) and scenes without the option: four.  A lit mesh's paths are long
-//    enough for pools to win at every length (unit_logo.yaml, one / four samples per launch: 430 -> 610 / 471 -> 750 Mpaths/s).
-static uint32_t pool_over_default(const ptx_ctx* c) {
+//  * A lit mesh's paths are long enough for pools to win at every length (unit_logo.yaml, one / four samples per launch:
+//    430 -> 610 / 471 -> 750 Mpaths/s).  Other scenes, when the options ask for pools at all: launches of more than four samples.
+static bool pools_by_default(const ptx_ctx* c, uint32_t n, bool big) {
     const bool lit_mesh = c->plain_mesh && c->sc.nlight > 0u;
-    if (c->opt.pool_over >= 0) return (uint32_t)c->opt.pool_over;
-    if (lit_mesh) return 0u;
-    if (c->sc.lds_scene_bytes > 0u && !c->sched && c->sc.has_fractals == 0u) return c->n_marched >= 2u ? 2u : 0u;
-    return 4u;
+    if (c->opt.pool_over >= 0) return n > (uint32_t)c->opt.pool_over;
+    if (lit_mesh) return true;
+    if (c->sc.lds_scene_bytes > 0u && c->sc.has_fractals == 0u) {
+        // Small scenes with a Moebius strip (wave-scheduled by the per-scene rule): every length too, now that short launches overlap
+        // -- 1080p, ms per launch of 1 / 2 / 4 samples back to back, wave-scheduled -> pools: all.yaml 1.83 / 3.30 / 6.26 -> 1.78 / 2.75 / 5.27,
+        // mebius.yaml 1.21 / 2.24 / 4.28 -> 1.16 / 1.89 / 3.56.
+        if (c->sched) return true;
+        if (c->n_marched >= 2u && n <= 2u) return false;
+        // ... and launches of three and four samples keep lane-owned paths when the scene is walls, a light and a figure or two
+        // (fewer than four primitives in the tree): there is little for a sort to bring together, and back to back the pools'
+        // rounds cost 6-12 % (cube.yaml 1.27 -> 1.39 ms at four samples per launch; the Cornell box 3.43 -> 2.89, demo.yaml
+        // 1.03 -> 0.65, and the scenes without lights, whose paths end after a bounce or two, 0.52 -> 0.42, gain).
+        if (n == 3u || n == 4u) return c->sc.nprim >= 4u || c->sc.nlight == 0u;
+        return true;
+    }
+    // Shallow meshes without lights (a bounce or two into the sky): launches of one and two samples, whose time under the
+    // wave-scheduled kernels is the hand-out of jobs and the launch's last waves -- 1080p, ms per launch of 1 / 2 samples back to
+    // back: teapot.yaml 0.45 / 0.66 -> 0.36 / 0.59, iron_man.yaml 0.43 / 0.51 -> 0.26 / 0.37, car.yaml 0.37 / 0.53 -> 0.35 / 0.52.
+    // At four samples pools win or lose by a third with the scene (teapot 1.13 -> 0.87, iron_man 0.65 -> 0.90), from five up they lose,
+    // and so do launches of more than PTX_MESH_POOL_JOBS jobs whatever their length: past the launch's start and end the
+    // wave-scheduled kernels trace a mesh faster (4K, one sample: teapot 1.20 -> 1.23 ms, iron_man 0.64 -> 0.76, car 0.88 -> 1.04).
+    if (c->plain_mesh) return (n <= 2u && !big) || n > 4u;
+    return n > 4u;
 }
-// ... and on those LDS scenes launches of three and four samples keep lane-owned paths when the scene is walls, a light and a
-// figure or two (fewer than four primitives in the tree): there is little for a sort to bring together, and back to back the pools'
-// rounds cost 6-12 % (cube.yaml 1.27 -> 1.39 ms at four samples per launch; the Cornell box 3.43 -> 2.89, demo.yaml 1.03 -> 0.65,
-// and the scenes without lights, whose paths end after a bounce or two, 0.52 -> 0.42, gain).
-static bool short_pools_pay(const ptx_ctx* c, uint32_t n) {
-    if (c->opt.pool_over >= 0 || n <= 2u || n > 4u) return true;
-    if (!(c->sc.lds_scene_bytes > 0u && !c->sched && c->sc.has_fractals == 0u)) return true;
-    return c->sc.nprim >= 4u || c->sc.nlight == 0u;
+// ... and on meshes without lights only those short launches do without being asked (options sorted_pool 1 + kernel_family 0 ask).
+static constexpr uint32_t PTX_MESH_POOL_JOBS = 4608u << 10;  // two samples of a 1080p frame, and a little
+static bool short_mesh_pools(const ptx_ctx* c, uint32_t n, bool big) {
+    return !big && c->plain_mesh && c->sc.nlight == 0u && c->opt.pool_over < 0 && n <= 2u;
 }
 
-static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
+// big: the launch has more jobs than the form for its length allows (LaunchForm::upto_jobs).
+static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed, bool big = false) {
     const DScene& sc = c->sc;
     const bool frac = sc.has_fractals != 0u, lds = sc.lds_scene_bytes > 0u;
     LaunchForm f;
@@ -1569,22 +1587,22 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
     // Shallow meshes with lights (unit_logo.yaml: six bounces and five occlusion queries per path) likewise: 72 -> 44 ms per 16
     // samples at 1080p; without lights (a bounce or two into the sky) the wave-scheduled kernels are up to twice as fast as pools.
     const bool lit_mesh = c->plain_mesh && sc.nlight > 0u;
-    const uint32_t pool_over = pool_over_default(c);
+    const bool by_default = pools_by_default(c, n, big), short_mesh = short_mesh_pools(c, n, big);
     // Sample jobs + fold against whole-pixel jobs: configure().  (Sample jobs need a claiming grid: below.)
     const bool can_split = samples_allowed && c->split && n <= c->split_upto;
-    const bool pools_instead = c->opt.family < 0 && c->opt.sorted_pool != 0 && (lds || lit_mesh) && !frac && n > pool_over && can_split && short_pools_pay(c, n);
+    const bool pools_instead = c->opt.family < 0 && c->opt.sorted_pool != 0 && (lds || lit_mesh || short_mesh) && !frac && by_default && can_split;
     f.sched = c->sched && !pools_instead;
     // The claiming kernels run a grid sized to the GPU: exactly the workgroups that are resident at once (a
     // workgroup that had to wait for another to finish would start its pre-assigned first jobs at the very end),
     // whose lanes claim pixels from a counter that starts behind the grid's own first jobs.  The pools' grid is the resident
     // workgroups too -- but only a launch that does trace from pools may be given that grid: the lockstep kernel for scenes in
     // global memory does not claim, it runs one workgroup per 16x16 block.
-    const bool pools_global = c->opt.sorted_pool == 1 || (c->opt.sorted_pool != 0 && lit_mesh && !f.sched);
-    f.claim = f.sched || (PTX_CLAIM_LDS && lds) || (pools_global && !frac && n > pool_over && can_split);
+    const bool pools_global = c->opt.sorted_pool == 1 || (c->opt.sorted_pool != 0 && (lit_mesh || short_mesh) && !f.sched);
+    f.claim = f.sched || (PTX_CLAIM_LDS && lds) || (pools_global && !frac && by_default && can_split);
     const bool split = f.claim && can_split;
     // Long launches of sample jobs on the lockstep kernels trace from sorted path pools (sorted_body); short ones, whose
     // time is the launch's first and last paths, keep the lane-owned form, which overlaps with its neighbours.
-    const bool sorted = split && !f.sched && !frac && n > pool_over && short_pools_pay(c, n) && (lds ? c->opt.sorted_pool != 0 : pools_global);
+    const bool sorted = split && !f.sched && !frac && by_default && (lds ? c->opt.sorted_pool != 0 : pools_global);
     f.jobs = sorted ? JOBS_POOLS : (split ? JOBS_SAMPLES : JOBS_PIXELS);
     f.kernel = f.sched == c->sched ? trace_kernel_of(c) : (lds ? ptx_trace_kernel_lds : ptx_trace_kernel);
     if (split && f.sched && !frac) f.kernel = lds ? ptx_sched_kernel_lds_samples : ptx_sched_kernel_samples;  // same registers, LDS and occupancy
@@ -1592,7 +1610,13 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
         f.kernel = lds ? ptx_trace_kernel_lds_sorted : ptx_trace_kernel_sorted;  // same LDS, four waves per SIMD
         // measured on the Cornell box, Gpath-bounce/s at 16 / 128 samples per launch: 1024 paths 11.6 / 12.3, 2048 12.2 / 13.2,
         // 4096 12.5 / 13.6, 8192 12.0 / 13.8, 16384 11.0 / 13.9 (a longer launch amortises a larger pool's first and last rounds)
-        f.pool_m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : 2048u));
+        // (one-sample launches of a mesh in global memory, 1024 against 2048: teapot.yaml 0.41 -> 0.36 ms, iron_man.yaml 0.29 -> 0.26)
+        f.pool_m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : (n == 1u && !lds ? 1024u : 2048u)));
+        // A pool's reservation samples the whole frame at a stride (job_pixel) in one-sample launches (Cornell box 0.857 -> 0.847 ms,
+        // rings.yaml 1.48 -> 0.91) and in two-sample launches of a mesh in global memory (iron_man.yaml 0.81 -> 0.37, teapot.yaml 0.62 -> 0.59);
+        // longer launches lose the locality of neighbouring pixels' staged samples (rings.yaml 128 samples 51.8 -> 55.4 ms).
+        f.upto_jobs = short_mesh && c->opt.sorted_pool != 1 ? PTX_MESH_POOL_JOBS : 0u;
+        f.spread = c->opt.pool_spread >= 0 ? c->opt.pool_spread != 0 : (n == 1u || (n == 2u && !lds));
     }
     // Deep trees: a wave's reservations start large and shrink with the jobs left, so its lanes stay on neighbouring pixels for
     // longer while the launch still ends evenly (all.yaml + 10 M triangles, 8 samples per launch: 36.6 -> 36.2 ms; shallow meshes,
@@ -1630,8 +1654,8 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed) {
 
 // The table: one row per class of launch length.  The thresholds are those form_for() compares n with.
 static void build_policy(ptx_ctx* c) {
-    const uint32_t pool_over = pool_over_default(c);
-    std::vector<uint32_t> upto = {1u, 2u, 4u, 16u, 63u, pool_over, c->split_upto, 0xFFFFFFFFu};  // the lengths form_for() compares n with
+    const uint32_t pool_over = c->opt.pool_over >= 0 ? (uint32_t)c->opt.pool_over : 0u;
+    std::vector<uint32_t> upto = {1u, 2u, 3u, 4u, 16u, 63u, pool_over, c->split_upto, 0xFFFFFFFFu};  // the lengths form_for() compares n with
     std::sort(upto.begin(), upto.end());
     upto.erase(std::unique(upto.begin(), upto.end()), upto.end());
     c->policy.clear();
@@ -1640,6 +1664,7 @@ static void build_policy(ptx_ctx* c) {
         PolicyRow r;
         r.upto = u;
         r.form = form_for(c, u, true);
+        r.big = r.form.upto_jobs ? form_for(c, u, true, true) : r.form;
         c->policy.push_back(r);
     }
     c->pixels_form = form_for(c, 1u, false);
@@ -1710,7 +1735,8 @@ static LaunchChoice resolve_launch(ptx_ctx* c, uint32_t n, bool fixed, uint32_t 
     for (const PolicyRow& r : c->policy)
         if (n <= r.upto) { row = &r; break; }
     // whole-pixel jobs: the static entry point (no staging buffer), radiance capture (its sample index is launch-relative), a launch alone
-    L.f = fixed || c->dbg || L.alone ? c->pixels_form : row->form;
+    const bool big = row->form.upto_jobs && (uint64_t)n_blocks * 256u * n > row->form.upto_jobs;
+    L.f = fixed || c->dbg || L.alone ? c->pixels_form : (big ? row->big : row->form);
     if (fixed && L.f.kernel == ptx_trace_kernel_lds_ranged) { L.f.kernel = ptx_trace_kernel_lds; L.f.counters = 1u; }  // its scratch array holds one counter
     L.chunk = n;
     L.depth = 1u;
@@ -1760,10 +1786,10 @@ static LaunchChoice resolve_launch(ptx_ctx* c, uint32_t n, bool fixed, uint32_t 
 static std::string describe_launch(const LaunchChoice& L) {
     char buf[256];
     const LaunchForm& f = L.f;
-    snprintf(buf, sizeof(buf), "%s jobs=%s claim_tile=%u counters=%u guided=%u paced=%u pool=%u flights=%u chunk=%u lds_stack=%u",
+    snprintf(buf, sizeof(buf), "%s jobs=%s claim_tile=%u counters=%u guided=%u paced=%u pool=%u spread=%u flights=%u chunk=%u lds_stack=%u",
              trace_kernel_label(f.kernel), f.jobs == JOBS_POOLS ? "pools" : (f.jobs == JOBS_SAMPLES ? "samples" : "pixels"), L.tile0,
              f.claim ? f.counters : 0u, f.claim && L.tile0 > 1u ? f.guided_k : 0u, f.claim && L.tile0 > 1u ? f.paced_m : 0u, f.pool_m,
-             f.jobs != JOBS_PIXELS ? L.depth : 0u, L.chunk, L.lds_stack);
+             f.jobs == JOBS_POOLS && f.spread ? 1u : 0u, f.jobs != JOBS_PIXELS ? L.depth : 0u, L.chunk, L.lds_stack);
     return buf;
 }
 
@@ -2151,9 +2177,7 @@ static int launch_trace(ptx_ctx* c, const ptx_camera* cam, uint32_t first_frame,
         P.pool_m = form.pool_m;
         P.pool_guided = c->opt.pool_guided >= 0 ? (uint32_t)c->opt.pool_guided : 0u;
         P.pool_finish = c->opt.pool_finish >= 0 ? (uint32_t)c->opt.pool_finish : 256u;
-        // one sample per launch: a pool's single reservation should sample the whole frame (Cornell box 0.857 -> 0.847 ms, rings.yaml
-        // 1.48 -> 0.91); longer launches lose the locality of neighbouring pixels' staged samples (rings.yaml 128 samples 51.8 -> 55.4 ms)
-        P.job_transposed = c->opt.pool_spread >= 0 ? (uint32_t)c->opt.pool_spread : (n == 1u ? 1u : 0u);
+        P.job_transposed = form.spread ? 1u : 0u;
     }
     const bool zero_based = kernel == ptx_trace_kernel_lds_ranged;
     const uint32_t ranges = form.counters;

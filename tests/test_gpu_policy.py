@@ -1,7 +1,7 @@
 """GPU tier: the launch policy is data.  For every scene fixture and launch length, what the policy's table says a launch
 would run (ptx_launch_plan) equals what tests/golden/launch_policy.json holds -- recorded on an MI355X from the launches
-themselves, by tools/record_launch_policy.py, before the policy became a table -- and equals what the launch then reports
-having run (ptx_last_launch_info).  The choice for a host that waits for every frame follows from the call sequence
+themselves, by tools/record_launch_policy.py, and re-recorded only when a choice is meant to change -- and equals what the
+launch then reports having run (ptx_last_launch_info).  The choice for a host that waits for every frame follows from the call sequence
 (read-backs between one-sample launches), not from a clock."""
 import json
 import os

@@ -73,7 +73,10 @@ def test_pools_over_scenes_read_from_global_memory(pt, name):
     assert _same(dflt, want)
     assert dflt[5] == {"teapot": "ptx_sched_kernel_samples", "unit_logo": "ptx_trace_kernel_sorted", "all": "ptx_trace_kernel_lds_sorted"}[name]
     short = _render(pt, sc, cam, w, h, [(0, 1, 3), (3, 4, 3)])
-    assert _same(short, want) and ("sched" in short[5]) == (name != "unit_logo")  # a lit mesh's paths are long enough for pools at every length
+    assert _same(short, want) and ("sched" in short[5]) == (name == "teapot")  # a lit mesh and the Moebius scenes: pools at every length
+    # launches of one and two samples back to back: pools on every one of them (a mesh without lights: up to a job count)
+    ones = _render(pt, sc, cam, w, h, [(0, 1, 1), (1, 2, 2), (3, 4, 1), (4, 5, 2)], host_waits_per_frame=0)
+    assert _same(ones, want) and "sorted" in ones[5]
     single = _render(pt, sc, cam, w, h, [(k, k + 1, 1) for k in range(n)], pool_over=0, kernel_family=0, sorted_pool=1, split_small=64)
     assert _same(single, want) and "sorted" in single[5]
 

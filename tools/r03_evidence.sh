@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3 measurement set on a GPU box.  usage: tools/r03_evidence.sh lines | profiles | phase
+# The measurement set kept under profiles/ (bench lines, kernel statistics, counter passes, pool phase cycles), on a GPU box.  usage: tools/r03_evidence.sh lines | profiles | phase
 #   lines     the default bench line (all four workloads, tolerance modes of the fractal workload) and the one-sample-per-launch lines
 #   profiles  rocprofv3 kernel trace + PMC passes of the four workloads (tools/profile_r02.sh; fractals with launches in turn)
 #   phase     cycles per phase of the Cornell box's pool kernel (diagnostic build -DPTX_PHASE_TIMING in pathtracer_amd/lib/diag/)

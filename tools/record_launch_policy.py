@@ -10,8 +10,8 @@ sys.path.insert(0, ROOT)
 from pathtracer_amd import host  # noqa: E402
 from pathtracer_amd.device import PathTracer  # noqa: E402
 
-LENGTHS = (1, 2, 4, 5, 16, 63, 64, 128)
-SIZES = ((64, 48), (1920, 1080))
+LENGTHS = (1, 2, 3, 4, 5, 16, 63, 64, 128)
+SIZES = ((64, 48), (1920, 1080), (3840, 2160))  # the largest: short launches whose job count is beyond what pools on a mesh take
 
 
 def describe(pt, wait_mode=None):
@@ -33,7 +33,7 @@ def main(out_path):
             cam = sc.camera(w, h)
             cam[0]["max_bounces"] = 2  # the policy does not look at it; keeps the recording short
             for n in LENGTHS:
-                if w > 64 and n > 5:
+                if (w > 64 and n > 5) or (w > 1920 and n > 2):
                     continue
                 pt.trace_n(cam, 0, 1, n)
                 pt.sync()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Short launches (1, 2, 4 samples) of every scene that runs the lockstep LDS kernels, at 1080p, back to back (64 launches) and in
-# turn: the default (sorted path pools with a pool set per flight) against lane-owned sample jobs (pool_over 4: round 2's default).
+# turn: the default (sorted path pools with a pool set per flight) against lane-owned sample jobs (pool_over 4).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 S="${SCENES:-aelita box cornell_box cube demo disc earth ellipsoid hyperboloid night paraboloid planet playground pyramid rings test tetrahedron torus}"
 for MODE in back_to_back in_turn; do
