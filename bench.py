@@ -34,7 +34,7 @@ WORKLOADS = {
 }
 # bounded CPU samples (whole frames, 5-30 s of work on the box's host cores): frames per workload
 CPU_FRAMES = {"cornell": 64, "teapot": 24, "fractals": 8, "all_mesh": 4}
-PEAK_FP32_VALU_TFLOPS = 157.3  # packed v_pk_fma_f32; 78.6 for one FMA per lane per clock
+PEAK_FP32_VALU_TFLOPS = 157.3  # 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz: the vector peak, reached by plain v_fma_f32 (a packed v_pk_fma_f32 issues at half the rate)
 PEAK_HBM_GBS = 8000.0
 METRIC = "Mpaths/s at 1080p (1/2/4/8 GPUs) + % FP32 VALU peak; image RMSE vs ref"
 
