@@ -126,18 +126,20 @@ const char* ptx_last_error(const ptx_ctx* ctx);
  *   share_walk, share_post, share_march, share_leaf   0 per scene, else 1..64: a state is served from 1/share of the live lanes
  *   walk_mode      -1 per scene, 0 a WALK step walks to a leaf primitive and tests it, 1 one node visit per step with
  *                  lanes at leaf primitives a state of their own, 2 walks to a leaf, tests wait as their own state
- *   sorted_pool    -1 per scene and launch (default: scenes staged in LDS that run the lockstep kernels trace every launch from sorted
- *                   path pools, shallow meshes with lights too, small scenes with a Moebius strip launches of more than four
- *                   samples; see ptx_trace_n), 0 never, 1 also scenes in global memory that run the lockstep kernels (kernel_family 0)
- *   pool_over      -1 per scene (default: 0 for scenes staged in LDS on the lockstep kernels -- 2 when several ray-marched figures
- *                   make pixels differ a hundredfold in cost -- and for shallow meshes with lights; else 4), else launches of more
- *                   samples than this may trace from pools (three- and four-sample launches of scenes with fewer than four
- *                   primitives in the tree keep lane-owned paths unless this option is set)
- *   pool_paths      0 = by launch length (2048 / 4096 / 8192 for up to 4 / under 64 / more samples, never more than the workgroup's
- *                   share of the launch's jobs), else paths per workgroup pool: a power of two from 256 to 16384
+ *   sorted_pool    -1 per scene and launch (default: scenes staged in LDS without fractals trace launches from sorted path pools,
+ *                   shallow meshes with lights too, shallow meshes without lights their one- and two-sample launches of up to
+ *                   4.6 M jobs; pool_over has the lengths, ptx_launch_plan shows the choice for a length), 0 never, 1 also scenes
+ *                   in global memory that run the lockstep kernels (kernel_family 0)
+ *   pool_over      -1 per scene (default: scenes staged in LDS and shallow meshes with lights: every length -- except that
+ *                   one- and two-sample launches of a lockstep scene with several ray-marched figures, whose pixels differ a
+ *                   hundredfold in cost, and three- and four-sample launches of one with fewer than four primitives in the tree keep
+ *                   lane-owned paths; other scenes, when sorted_pool asks for pools at all: more than four samples), else launches
+ *                   of more samples than this trace from pools
+ *   pool_paths      0 = by launch length (2048 / 4096 / 8192 for up to 4 / under 64 / more samples, 1024 for one-sample launches of a
+ *                   scene in global memory; never more than the workgroup's share of the launch's jobs), else paths per workgroup pool: a power of two from 256 to 16384
  *   pool_finish    -1 = 256; with no job left to reserve, a pool of up to this many paths is traced to the end without further rounds
  *   pool_guided    -1 = 0: a top-up reserves what the pool lacks; k = 1..64: at most 1/(k * workgroups) of the jobs left
- *   pool_spread    -1 one-sample launches only (default), 1 / 0: a pool's reservation samples the frame at a stride of sixteen pixels
+ *   pool_spread    -1 one-sample launches, and two-sample launches of scenes in global memory (default), 1 / 0: a pool's reservation samples the frame at a stride of sixteen pixels
  *                   instead of taking neighbouring 16x16 blocks
  *   grid_per_cu     0 = every resident workgroup, else workgroups per compute unit
  *   flights         launches of sample-granular jobs that may overlap: 0 = per launch (fractal scenes and lane-owned launches of up to
