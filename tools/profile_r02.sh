@@ -40,6 +40,8 @@ if 'GRBM_GUI_ACTIVE' in g and 'SQ_ACTIVE_INST_VALU' in g:
     derived = {"valu_busy_frac": round(g['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles, 4),
                "lane_utilisation": round(g['SQ_THREAD_CYCLES_VALU'] / (g['SQ_ACTIVE_INST_VALU'] * 64), 4),
                "salu_per_valu": round(g.get('SQ_INSTS_SALU', 0) / max(g['SQ_INSTS_VALU'], 1), 4),
+               # instructions issued per SIMD cycle (a SIMD issues a wave64 v_fma_f32 every 2.5 cycles at best, a scalar instruction every 4.3: tools/probes/issue_probe.hip)
+               "valu_per_simd_cycle": round(g['SQ_INSTS_VALU'] / simd_cycles, 4), "salu_per_simd_cycle": round(g.get('SQ_INSTS_SALU', 0) / simd_cycles, 4),
                "lds_bank_conflict_frac": round(g.get('SQ_LDS_BANK_CONFLICT', 0) / max(g.get('SQ_ACTIVE_INST_LDS', 1), 1), 4)}
 if 'FETCH_SIZE' in g and 'WRITE_SIZE' in g:
     # KB per dispatch; FETCH_SIZE is doubled (the counter counts 64 B requests as 32 B on gfx950)

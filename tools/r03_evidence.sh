@@ -21,6 +21,10 @@ elif [ "$PART" = profiles ]; then
   done
   bash tools/profile_r02.sh fractals --opt flights=1 > $O/prof_fractals.txt 2>&1 || { echo "fractals profile failed"; tail -5 $O/prof_fractals.txt; exit 1; }
   tail -1 $O/prof_fractals.txt
+  # the reference's own dispatch: one-sample launches of the Cornell box back to back (kernel trace only: the launches overlap)
+  export TMPDIR=/tmp
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_spp1 -o trace -- python3 bench.py --workload cornell --spp-per-step 1 --steps 64 --warmup 4 --no-cpu-baseline > $O/trace_spp1.log 2>&1 || { echo "spp1 trace failed"; tail -5 $O/trace_spp1.log; exit 1; }
+  grep -h "^\"ptx_\|^\"Name" $(find $O/trace_spp1 -name "*kernel_stats.csv") > $O/kernel_stats_cornell_spp1.txt; cat $O/kernel_stats_cornell_spp1.txt
 else
   PTX355_LIB=pathtracer_amd/lib/diag/libptx355_phase.so PROBE_N=1,16,128 timeout -k 10 200 python3 tools/perf_probe.py cornell_box > $O/phase_cornell.txt 2>&1 || { echo "phase probe failed"; exit 1; }
   cat $O/phase_cornell.txt
