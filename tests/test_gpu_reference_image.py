@@ -1,0 +1,82 @@
+"""GPU tier: the HIP kernels render the picture the reference repository holds (resources/cornell_box.png, its README's image of the
+Cornell box from the reference's own wgpu / WGSL pipeline) -- block for block.  What the picture is, which scene it shows and how
+that was established: tests/test_reference_image.py.  Here the frame is rendered at the picture's size, 1920x1080, with 2048
+samples per pixel, tone-mapped by the library, and its 8x8 block means are compared with the picture's in 8-bit levels."""
+import numpy as np
+import pytest
+
+from pathtracer_amd import host
+from pathtracer_amd.device import PathTracer
+from test_reference_image import CEILING_LIGHT, PICTURE_STRENGTH, REF_BLOCKS, SECOND_LIGHT
+from util import fixture
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+REGIONS = {  # 8x8 blocks: rows, columns
+    "red wall": (slice(40, 95), slice(5, 55)), "green wall": (slice(40, 95), slice(185, 235)), "back wall": (slice(40, 60), slice(90, 150)),
+    "floor": (slice(120, 133), slice(70, 170)), "ceiling": (slice(2, 15), slice(70, 170)), "light": (slice(20, 27), slice(108, 132)),
+    "glass sphere": (slice(85, 105), slice(85, 108)), "gold sphere": (slice(95, 110), slice(138, 155)), "cube": (slice(94, 104), slice(115, 125)),
+    "ellipsoid": (slice(64, 78), slice(116, 123))}
+
+
+@pytest.fixture(scope="module")
+def pt():
+    t = PathTracer(0)
+    yield t
+    t.reset_options()
+    t.close()
+
+
+def _blocks(pt, drop, strength, n):
+    d = np.load(fixture("cornell_box"), allow_pickle=False)
+    keep = [i for i in range(len(d["figs"])) if i not in drop]
+    mats = d["mats"].copy()
+    assert mats["emission_strength"][CEILING_LIGHT] == 8.0 and mats["emission_strength"][SECOND_LIGHT] == 6.0
+    mats["emission_strength"][CEILING_LIGHT] = strength
+    sc = host.Scene.empty()
+    sc.append_shapes(d["figs"][keep], mats[keep])
+    cam = d["camera"]
+    sc.set_camera(cam[0:3], cam[3:6], float(cam[6]))
+    sc.set_render_settings(max_bounces=int(cam[8]), fractal_march_steps=int(cam[15]), tone_mapper=int(cam[14]), firefly_clamp=float(cam[9]), exposure=float(cam[7]))
+    sc.set_sky(cam[10:13], float(cam[13]))
+    sc.build()
+    pt.reset_options()
+    sc.upload_to(pt)
+    pt.resize(W, H)
+    c = sc.camera(W, H)
+    done = 0
+    while done < n:
+        m = min(128, n - done)
+        pt.trace_n(c, done, done + 1, m)
+        done += m
+    img = pt.read_output().reshape(H, W, 4)[:, :, :3].astype(np.float64)
+    return img.reshape(H // 8, 8, W // 8, 8, 3).mean(axis=(1, 3))
+
+
+def test_hip_render_equals_the_reference_picture(pt):
+    ref = np.load(REF_BLOCKS).astype(np.float64)
+    ours = _blocks(pt, {SECOND_LIGHT}, PICTURE_STRENGTH, 2048)
+    d = ours - ref
+    worst = np.abs(d).max(axis=2)
+    # measured with 4096 samples: 0.17 levels on average, 97.5 % of the 32 400 blocks within one level, 99.7 % within two, all within four
+    assert np.abs(d).mean() < 0.35, np.abs(d).mean()
+    assert abs(d.mean()) < 0.15, d.mean()
+    assert (worst <= 1.0).mean() > 0.93 and (worst <= 2.0).mean() > 0.99 and worst.max() < 6.0, ((worst <= 1.0).mean(), (worst <= 2.0).mean(), worst.max())
+    assert np.sqrt((d * d).mean()) / ref.mean() < 0.005
+    for name, (r, c) in REGIONS.items():
+        delta = np.abs(ours[r, c].mean(axis=(0, 1)) - ref[r, c].mean(axis=(0, 1))).max()
+        assert delta < (2.0 if name in ("gold sphere", "cube") else 0.5), (name, delta)
+
+
+@pytest.mark.parametrize("drop,strength,least", [((), 8.0, 10.0), ((SECOND_LIGHT,), 8.0, 30.0), ((SECOND_LIGHT, 9), PICTURE_STRENGTH, None),
+                                                  ((SECOND_LIGHT, 10), PICTURE_STRENGTH, None), ((SECOND_LIGHT, 8), PICTURE_STRENGTH, None)])
+def test_other_scenes_are_not_the_picture(pt, drop, strength, least):
+    """The comparison has the power to tell: today's file (second light, ceiling light at 8), today's ceiling light alone, and the
+    picture's scene without its torus, its pyramid or its cube are all far from the picture."""
+    ref = np.load(REF_BLOCKS).astype(np.float64)
+    ours = _blocks(pt, set(drop), strength, 256)
+    d = np.abs(ours - ref)
+    if least is not None:
+        assert d.mean() > least, d.mean()
+    else:
+        assert d.max() > 15.0 and (d.max(axis=2) > 8.0).sum() >= 4, d.max()

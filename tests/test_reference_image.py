@@ -1,0 +1,99 @@
+"""The one rendered image the reference repository holds -- resources/cornell_box.png, its README's picture of the Cornell box,
+1920x1080, made by the reference's own wgpu / WGSL pipeline -- against this repository's CPU oracle (here) and HIP kernels
+(test_gpu_reference_image.py).  The fixture is tests/golden/reference_cornell_box_blocks.npy: the picture's 8x8 block means
+(tools/make_reference_image_golden.py).
+
+The picture predates two edits of resources/scenes/cornell_box.yaml: it has no second light (today's last figure, the small
+emissive sphere) and its ceiling light has emission_strength 3 where the file now says 8.  Neither is recorded anywhere; both
+follow from the picture: with today's file every wall, the floor, the ceiling and the glass figures are brighter than the
+picture by one common factor in linear radiance -- 2.65 +- 0.03 across ten regions and three channels once the second light is
+removed (8 / 3 = 2.67), and by factors between 1.15 and 1.44 with it -- and with those two values the render below matches the
+picture to a sixth of an 8-bit level on average, with every figure of the scene in place (leaving out the torus, the pyramid or
+the cube moves blocks by 17 to 55 levels).  Two fitted values against 97 200 block colours: camera, the six intersectors in view
+(plane, disc, sphere, cube, pyramid, ellipsoid) and the torus marcher, glass, metal and diffuse materials, next-event estimation
+with the reference's light-count weighting, roulette, firefly clamp, the ACES curve and the sRGB transfer all have to agree for
+that.  This is a statistical pin (the picture's sample count and noise are unknown), not a bit-exact one."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import host_prep as hp, oracle as orc
+from util import GOLDEN_DIR, fixture
+
+REF_BLOCKS = os.path.join(GOLDEN_DIR, "reference_cornell_box_blocks.npy")
+SECOND_LIGHT, CEILING_LIGHT, PICTURE_STRENGTH = 12, 5, 3.0  # figure indices in cornell_box.yaml; the strength the picture was made with
+REGIONS = {  # 8x8 blocks of the 1080p picture: rows, columns
+    "red wall": (slice(40, 95), slice(5, 55)), "green wall": (slice(40, 95), slice(185, 235)), "back wall": (slice(40, 60), slice(90, 150)),
+    "floor": (slice(120, 133), slice(70, 170)), "ceiling": (slice(2, 15), slice(70, 170)), "glass sphere": (slice(85, 105), slice(85, 108)),
+    "ellipsoid": (slice(64, 78), slice(116, 123))}
+
+
+def picture_scene_shapes():
+    """The scene the picture shows: today's cornell_box.yaml without its second light, ceiling light at strength 3."""
+    shapes, cam, loader = hp.scene_from_fixture(fixture("cornell_box"))
+    assert shapes[SECOND_LIGHT].shape_type == "sphere" and shapes[SECOND_LIGHT].material.emission_strength == 6.0
+    assert shapes[CEILING_LIGHT].shape_type == "disc" and shapes[CEILING_LIGHT].material.emission_strength == 8.0
+    shapes = shapes[:SECOND_LIGHT]
+    shapes[CEILING_LIGHT].material.emission_strength = PICTURE_STRENGTH
+    return shapes, cam, loader
+
+
+def smooth_blocks(ref: np.ndarray, levels: float = 3.0) -> np.ndarray:
+    """Blocks whose four neighbours are within `levels` of them: there the mean of tone-mapped pixels equals the tone-mapped mean."""
+    m = np.ones(ref.shape[:2], dtype=bool)
+    for ax, sh in ((0, 1), (0, -1), (1, 1), (1, -1)):
+        m &= np.abs(ref - np.roll(ref, sh, axis=ax)).max(axis=2) <= levels
+    m[0, :] = m[-1, :] = False
+    m[:, 0] = m[:, -1] = False
+    return m
+
+
+def test_the_fixture_is_the_picture():
+    ref = np.load(REF_BLOCKS)
+    assert ref.shape == (135, 240, 3) and ref.dtype == np.float32
+    # the red wall, the green wall and the light, as anyone sees them in the README
+    assert ref[67, 20, 0] > 120 and ref[67, 20, 1] < 40 and ref[67, 220, 1] > 120 and ref[67, 220, 0] < 40 and ref[23, 120].min() > 245
+
+
+def srgb_to_linear(levels):
+    c = np.asarray(levels, dtype=np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def aces_inverse(y):
+    """x with y = x (2.51 x + 0.03) / (x (2.43 x + 0.59) + 0.14): tonemap.wgsl's curve, solved for its argument."""
+    a, b, c = 2.51 - 2.43 * y, 0.03 - 0.59 * y, -0.14 * y
+    return (-b + np.sqrt(b * b - 4.0 * a * c)) / (2.0 * a)
+
+
+def picture_radiance(ref):
+    """Linear radiance of the picture's blocks (exposure 1): exact where a block is smooth, and meaningless where it is saturated."""
+    return aces_inverse(srgb_to_linear(ref))
+
+
+def test_oracle_renders_the_reference_picture():
+    """The CPU oracle at 240x135 -- one pixel per 8x8 block of the picture, the camera's jitter covering exactly that block -- against
+    the picture's radiance where the picture is smooth and unsaturated.  In linear radiance, because the mean of 256 samples is
+    unbiased there (a tone curve applied to a noisy mean is not)."""
+    ref = np.load(REF_BLOCKS).astype(np.float64)
+    shapes, cam, loader = picture_scene_shapes()
+    sb = hp.prepare_shapes(shapes, cam, loader)
+    w, h, n = 240, 135, 256
+    m = smooth_blocks(ref) & (ref.max(axis=2) < 240.0)
+    assert m.mean() > 0.6
+    want = picture_radiance(ref)
+    ours = orc.render(orc.OracleScene(sb), hp.camera_to_gpu(cam, w, h), n)["accum"][:, :, :3].astype(np.float64)
+    ratio = ours[m].mean(axis=0) / want[m].mean(axis=0)
+    assert np.abs(ratio - 1.0).max() < 0.015, ratio                       # measured: 1.001, 1.003, 1.005
+    for name, (r, c) in REGIONS.items():
+        mm = m[r, c]
+        if mm.sum() < 300:
+            continue
+        rr = ours[r, c][mm].mean(axis=0) / want[r, c][mm].mean(axis=0)
+        assert np.abs(rr - 1.0).max() < 0.04, (name, rr)                   # measured: within 2 % (noise of 256 samples)
+    assert np.median(np.abs(ours[m] - want[m]) / want[m]) < 0.15            # block by block: the noise of 256 samples, no more
+    # today's file is not the picture: the same comparison is off by a factor
+    today = hp.prepare_fixture(fixture("cornell_box"))
+    ours2 = orc.render(orc.OracleScene(today), hp.camera_to_gpu(cam, w, h), 32)["accum"][:, :, :3].astype(np.float64)
+    assert (ours2[m].mean(axis=0) / want[m].mean(axis=0)).min() > 1.2
