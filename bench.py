@@ -348,6 +348,45 @@ def run_workload(name: str, args, D: Dist, steps: int, warmup: int, spp_override
     return out
 
 
+def reference_picture_check(spp: int = 2048) -> dict:
+    """The HIP kernels' 1080p frame of the scene that the reference's own picture shows (resources/cornell_box.png: today's
+    cornell_box.yaml without its second light, ceiling light at strength 3; tests/test_reference_image.py has the derivation)
+    against the picture's 8x8 block means (tests/golden/reference_cornell_box_blocks.npy), in 8-bit levels.  Not timed."""
+    import numpy as np
+    from pathtracer_amd import host
+    from pathtracer_amd.device import PathTracer
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "reference_cornell_box_blocks.npy")).astype(np.float64)
+    d = np.load(os.path.join(ROOT, "data", "scenes", "cornell_box.npz"), allow_pickle=False)
+    second_light, ceiling_light = 12, 5
+    keep = [i for i in range(len(d["figs"])) if i != second_light]
+    mats = d["mats"].copy()
+    mats["emission_strength"][ceiling_light] = 3.0
+    sc = host.Scene.empty()
+    sc.append_shapes(d["figs"][keep], mats[keep])
+    cam = d["camera"]
+    sc.set_camera(cam[0:3], cam[3:6], float(cam[6]))
+    sc.set_render_settings(max_bounces=int(cam[8]), fractal_march_steps=int(cam[15]), tone_mapper=int(cam[14]), firefly_clamp=float(cam[9]), exposure=float(cam[7]))
+    sc.set_sky(cam[10:13], float(cam[13]))
+    sc.build()
+    w, h = 1920, 1080
+    pt = PathTracer(0)
+    sc.upload_to(pt)
+    pt.resize(w, h)
+    c = sc.camera(w, h)
+    for first in range(0, spp, 128):
+        pt.trace_n(c, first, first + 1, min(128, spp - first))
+    img = pt.read_output().reshape(h, w, 4)[:, :, :3].astype(np.float64)
+    pt.close()
+    ours = img.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+    diff = ours - ref
+    worst = np.abs(diff).max(axis=2)
+    return {"picture": "the reference repository's resources/cornell_box.png (its README's render), 8x8 block means", "samples_per_pixel": spp,
+            "mean_abs_error_levels": round(float(np.abs(diff).mean()), 4), "bias_levels": round(float(diff.mean()), 4),
+            "relative_rmse": round(float(np.sqrt((diff * diff).mean()) / ref.mean()), 5),
+            "blocks_within_1_2_4_levels": [round(float((worst <= t).mean()), 4) for t in (1.0, 2.0, 4.0)], "worst_block_levels": round(float(worst.max()), 2),
+            "blocks": int(worst.size)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,6 +431,10 @@ def main():
             except Exception as e:  # noqa: BLE001  a leg that fails must not lose the headline line
                 others[name] = {"error": f"{type(e).__name__}: {e}"}
         out["other_workloads"] = others
+        try:  # the one output of the reference's own pipeline that exists, against this library's render of the same scene
+            out["reference_picture"] = reference_picture_check()
+        except Exception as e:  # noqa: BLE001
+            out["reference_picture"] = {"error": f"{type(e).__name__}: {e}"}
     if D.rank == 0:
         print(json.dumps(out), flush=True)
     D.close()
