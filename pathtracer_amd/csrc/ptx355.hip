@@ -1611,12 +1611,14 @@ static LaunchForm form_for(const ptx_ctx* c, uint32_t n, bool samples_allowed, b
         // measured on the Cornell box, Gpath-bounce/s at 16 / 128 samples per launch: 1024 paths 11.6 / 12.3, 2048 12.2 / 13.2,
         // 4096 12.5 / 13.6, 8192 12.0 / 13.8, 16384 11.0 / 13.9 (a longer launch amortises a larger pool's first and last rounds)
         // (one-sample launches of a mesh in global memory, 1024 against 2048: teapot.yaml 0.41 -> 0.36 ms, iron_man.yaml 0.29 -> 0.26)
-        f.pool_m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : (n == 1u && !lds ? 1024u : 2048u)));
+        const bool unlit_mesh = !lds && !lit_mesh;  // paths of a bounce or two: a launch is over before a large pool has been filled twice
+        f.pool_m = c->opt.pool_paths ? c->opt.pool_paths : (n >= 64u ? 8192u : (n > 4u ? 4096u : (n == 1u && unlit_mesh ? 1024u : 2048u)));
         // A pool's reservation samples the whole frame at a stride (job_pixel) in one-sample launches (Cornell box 0.857 -> 0.847 ms,
         // rings.yaml 1.48 -> 0.91) and in two-sample launches of a mesh in global memory (iron_man.yaml 0.81 -> 0.37, teapot.yaml 0.62 -> 0.59);
         // longer launches lose the locality of neighbouring pixels' staged samples (rings.yaml 128 samples 51.8 -> 55.4 ms).
         f.upto_jobs = short_mesh && c->opt.sorted_pool != 1 ? PTX_MESH_POOL_JOBS : 0u;
-        f.spread = c->opt.pool_spread >= 0 ? c->opt.pool_spread != 0 : (n == 1u || (n == 2u && !lds));
+        // A lit mesh's long paths want neither (unit_logo.yaml, one / two samples: 3.05 / 5.59 ms with both, 2.77 / 5.38 with pools of 2048 in block order).
+        f.spread = c->opt.pool_spread >= 0 ? c->opt.pool_spread != 0 : (lit_mesh ? false : (n == 1u || (n == 2u && unlit_mesh)));
     }
     // Deep trees: a wave's reservations start large and shrink with the jobs left, so its lanes stay on neighbouring pixels for
     // longer while the launch still ends evenly (all.yaml + 10 M triangles, 8 samples per launch: 36.6 -> 36.2 ms; shallow meshes,
