@@ -348,10 +348,11 @@ def run_workload(name: str, args, D: Dist, steps: int, warmup: int, spp_override
     return out
 
 
-def reference_picture_check(spp: int = 2048) -> dict:
+def reference_picture_check(spp: int = 3272) -> dict:
     """The HIP kernels' 1080p frame of the scene that the reference's own picture shows (resources/cornell_box.png: today's
     cornell_box.yaml without its second light, ceiling light at strength 3; tests/test_reference_image.py has the derivation)
-    against the picture's 8x8 block means (tests/golden/reference_cornell_box_blocks.npy), in 8-bit levels.  Not timed."""
+    against the picture's 8x8 block means (tests/golden/reference_cornell_box_blocks.npy), in 8-bit levels.  3272 samples from frame
+    index 0: the picture's own count, where the two frames share their noise (tests/test_gpu_reference_image.py).  Not timed."""
     import numpy as np
     from pathtracer_amd import host
     from pathtracer_amd.device import PathTracer

@@ -12,7 +12,9 @@ picture to a sixth of an 8-bit level on average, with every figure of the scene 
 the cube moves blocks by 17 to 55 levels).  Two fitted values against 97 200 block colours: camera, the six intersectors in view
 (plane, disc, sphere, cube, pyramid, ellipsoid) and the torus marcher, glass, metal and diffuse materials, next-event estimation
 with the reference's light-count weighting, roulette, firefly clamp, the ACES curve and the sRGB transfer all have to agree for
-that.  This is a statistical pin (the picture's sample count and noise are unknown), not a bit-exact one."""
+that.  The GPU tier goes one step further (test_the_pictures_noise_is_this_librarys_noise): the picture is the mean of about 3276
+frames drawn with the very random sequences this library draws.  A statistical pin all the same -- one scene, and the author's GPU
+does not round transcendentals as the oracle does -- not a bit-exact one."""
 import os
 
 import numpy as np
