@@ -81,6 +81,9 @@ PT_DEV float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 // (1 ulp, flushing) plus one fused Newton step plus v_div_fixup gives: 4 instructions instead of the 11 of
 // an IEEE divide.  ptx_kat_exhaustive (ptx355.hip) checks it against the definition over all 2^32 inputs.
 PT_DEV float rcp_(float y) {
+#ifdef PT_HW_APPROX  // experiment only: the hardware's 1-ulp estimates, as a shader compiler emits them for WGSL's division and sqrt
+    return __builtin_amdgcn_rcpf(y);
+#endif
     float r = __builtin_amdgcn_rcpf(y);
     float e = __builtin_fmaf(-y, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
@@ -91,6 +94,9 @@ PT_DEV float div_(float x, float y) { return x * rcp_(y); }
 // fused residual step is correctly rounded (same exhaustive check); the rest (zeros, subnormal and tiny
 // inputs whose residual would underflow, infinity, NaN, negative inputs) takes the compiler's long sequence.
 PT_DEV float sqrt_(float x) {
+#ifdef PT_HW_APPROX
+    return __builtin_amdgcn_sqrtf(x);
+#endif
     if (__builtin_expect((__float_as_uint(x) - 0x0C800000u) >= (0x7F800000u - 0x0C800000u), 0)) return __builtin_sqrtf(x);
     float r = __builtin_amdgcn_rsqf(x);
     float g = x * r, h = 0.5f * r;
@@ -342,7 +348,11 @@ PT_DEV V3 cross(V3 a, V3 b) {
 }
 PT_DEV V3 madd(V3 o, V3 d, float t) { return v3(dm::fma_(d.x, t, o.x), dm::fma_(d.y, t, o.y), dm::fma_(d.z, t, o.z)); }
 PT_DEV float length(V3 a) { return dm::sqrt_(dot(a, a)); }
+#ifdef PT_NORMALIZE_RSQ  // experiment only: the hardware's reciprocal square root (1 ulp), as a shader compiler may emit for normalize()
+PT_DEV V3 normalize(V3 a) { float inv = __builtin_amdgcn_rsqf(dot(a, a)); return a * inv; }
+#else
 PT_DEV V3 normalize(V3 a) { float inv = dm::rcp_(dm::sqrt_(dot(a, a))); return a * inv; }
+#endif
 // vector / scalar = vector * (1 / scalar): one correctly rounded reciprocal, then three multiplies.
 PT_DEV V3 vdivs(V3 a, float s) { float inv = dm::rcp_(s); return a * inv; }
 PT_DEV V3 vabs(V3 a) { return v3(dm::abs_(a.x), dm::abs_(a.y), dm::abs_(a.z)); }

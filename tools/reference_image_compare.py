@@ -7,7 +7,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pathtracer_amd import host  # noqa: E402
+from pathtracer_amd import host, _lib  # noqa: E402
+if os.environ.get("PTX355_LIB"):  # a differently built library (arithmetic experiments)
+    _lib.LIB_PATH = os.path.abspath(os.environ["PTX355_LIB"])
 from pathtracer_amd.device import PathTracer  # noqa: E402
 
 REGIONS = {  # in 8x8 blocks: rows, columns
